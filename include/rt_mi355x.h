@@ -1,0 +1,187 @@
+/* rt_mi355x.h — C ABI of the MI355X (gfx950) path-tracing backend.
+ *
+ * Drop-in boundary for the render path of nabilbrice/raytracer: the Rust crate
+ * keeps Config / SetupCamera / Camera / Shape / Material and its PPM writer and
+ * calls these entry points in place of raytracer::accel_render_into_file
+ * (src/lib.rs:159-184) and raytracer::render_into_file (src/lib.rs:137-157).
+ * Plain C: POD structs, pointers and sizes only.  Every function that can fail
+ * returns an int status (RT_OK = 0) and never unwinds across the boundary; the
+ * reference signals the same conditions with panics.  rt_last_error() gives the
+ * message of the calling thread's last failure.
+ *
+ * A scene handle is not thread-safe: one call at a time per handle.
+ */
+#ifndef RT_MI355X_H
+#define RT_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARGUMENT = 1, /* null pointer, zero resolution, empty sample range, bad index ... */
+    RT_ERR_UNSUPPORTED = 2,      /* shape / material outside src/geometry.rs:9-15, src/materials.rs:15-35 */
+    RT_ERR_DEVICE = 3,           /* no gfx950 device, HIP call failed */
+    RT_ERR_IO = 4,               /* file could not be opened / written / parsed */
+    RT_ERR_LIMIT = 5             /* size beyond what an entry point supports */
+};
+
+enum rt_shape_kind { RT_SHAPE_SPHERE = 0, RT_SHAPE_DISC = 1 }; /* src/geometry.rs:9-15 (BoundVolume is serde-skipped) */
+enum rt_material_kind {                                        /* src/materials.rs:15-35 */
+    RT_MAT_DIFFUSE = 0,
+    RT_MAT_METAL = 1,
+    RT_MAT_DIELECTRIC = 2,
+    RT_MAT_TEXTUREMAP = 3,
+    RT_MAT_EMITTER = 4
+};
+
+/* src/camera.rs:4-16, field for field. */
+typedef struct rt_camera {
+    double lookat[3];
+    double lookfrom[3];
+    double lookup[3];
+    double focal_distance;
+    double inv_focal_length;
+    double aperture;
+    double horiz_arm[3];
+    double vert_arm[3];
+    uint32_t horiz_res;
+    uint32_t vert_res;
+    double aspect_ratio; /* computed and never used, as in src/camera.rs:33 */
+} rt_camera;
+
+/* src/lib.rs:25-29 Hittable {shape, material}, flattened.  The primitive ID of a
+ * hittable is its index in the array handed to rt_scene_create (the order of
+ * scene.push in src/scenegen.rs:23-61, or of "hittables" in scene.json). */
+typedef struct rt_hittable {
+    int32_t shape;           /* rt_shape_kind */
+    int32_t material;        /* rt_material_kind */
+    double centre[3];        /* src/geometry.rs:38, :44 */
+    double normal[3];        /* disc only; used as given (serde bypasses Disc::new, src/geometry.rs:42-47) */
+    double radius;           /* src/geometry.rs:39, :46 */
+    double albedo[3];        /* Diffuse, Metal, Emitter */
+    double fuzz;             /* Metal */
+    double refractive_index; /* Dielectric */
+    double orient_up[3];     /* TextureMap */
+    double orient_around[3]; /* TextureMap */
+    int32_t texture;         /* TextureMap: index into the texture table, else -1 */
+    int32_t reserved;
+} rt_hittable;
+
+/* Decoded image of a TextureMap ("map" in src/materials.rs:26-31): 8-bit RGB,
+ * row-major, row 0 = top, no padding. */
+typedef struct rt_texture {
+    const uint8_t* rgb8;
+    uint32_t width;
+    uint32_t height;
+} rt_texture;
+
+typedef struct rt_scene rt_scene; /* opaque: flattened BVH + SoA primitives resident in HBM */
+
+typedef struct rt_scene_info {
+    uint64_t n_hittables, n_spheres, n_discs;
+    uint64_t n_nodes;      /* inner nodes of the flattened two-child BVH (leaves live in their parent) */
+    uint32_t bvh_depth;    /* inner-node levels */
+    uint32_t stack_depth;  /* traversal stack entries per lane compiled for this scene */
+    uint64_t device_bytes; /* HBM held by the scene */
+    double build_seconds;  /* host BVH build + flatten + upload */
+    int32_t device;
+    int32_t lds_resident;  /* 1 when nodes and spheres are staged in LDS by the render kernel */
+} rt_scene_info;
+
+/* Sample range and launch options of one render call. */
+typedef struct rt_render_opts {
+    uint32_t sample_begin; /* first sample index of every pixel traced by this call */
+    uint32_t sample_end;   /* one past the last; sample_end - sample_begin paths per pixel */
+    uint32_t depth;        /* scatter_depth of src/lib.rs:88 (the reference passes 10, src/lib.rs:172) */
+    uint32_t flags;        /* RT_RENDER_* */
+    uint64_t seed;         /* Philox4x32-10 key; counter = (pixel, sample, bounce, attempt) */
+} rt_render_opts;
+enum { RT_RENDER_ACCUMULATE = 1 /* add to the buffer instead of overwriting it */ };
+
+const char* rt_last_error(void);
+
+/* Version of this ABI (major << 16 | minor). */
+uint32_t rt_abi_version(void);
+
+/* Number of usable gfx950 devices; 0 when there is none. */
+int rt_device_count(void);
+
+/* src/camera.rs:19-47 Camera::build. */
+int rt_camera_build(const double lookat[3], const double lookfrom[3], double inv_focal_length, double aperture,
+                    uint32_t horiz_res, uint32_t vert_res, rt_camera* out);
+
+/* src/scenegen.rs:70-79 default_camera with the resolution as arguments (the reference fixes 512 x 512). */
+int rt_default_camera(uint32_t horiz_res, uint32_t vert_res, rt_camera* out);
+
+/* src/scenegen.rs:12-109 gen_scene: 488 hittables in push order.  The reference
+ * draws from an unseeded ThreadRng; here a SplitMix64 stream seeded by `seed`
+ * is used in the same draw order.  Writes at most cap entries, *n = 488. */
+int rt_gen_scene(uint64_t seed, rt_hittable* out, size_t cap, size_t* n);
+
+/* Build-defined stress scenes made only of the reference's shapes and materials.
+ * grid: ground sphere + side*side small spheres (r = 0.2) resting on it, the
+ * material mix of gen_scene.  shells: the scene.json earth sphere (texture 0) +
+ * `shells` concentric dielectric spheres with alternating index 1.5 / (1/1.5). */
+int rt_gen_scene_grid(uint64_t seed, uint32_t side, rt_hittable* out, size_t cap, size_t* n);
+int rt_gen_scene_shells(uint32_t shells, rt_hittable* out, size_t cap, size_t* n);
+
+/* Box<[Hittable]> / Box<CoveringTree> of src/main.rs:10-13: copies the inputs,
+ * builds and flattens the BVH (replaces make_coveringtree,
+ * src/boundingvolume.rs:192-208) and uploads everything to `device`.
+ * Discs are kept outside the BVH and tested one by one, as src/lib.rs:46-49 does. */
+int rt_scene_create(const rt_hittable* hittables, size_t n_hittables, const rt_texture* textures, size_t n_textures,
+                    int device, rt_scene** out);
+void rt_scene_destroy(rt_scene* scene);
+int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out);
+
+/* accel_render_into_file / render_into_file (src/lib.rs:137-184) without the
+ * file: traces samples [sample_begin, sample_end) of every pixel and leaves the
+ * per-pixel SUM of the path colours, 3 floats per pixel, row-major with row 0 at
+ * the top (src/lib.rs:166-167), in d_sum_rgb — DEVICE memory of the scene's
+ * device.  `stream` is a hipStream_t (NULL = default stream); the call is
+ * asynchronous with respect to the host. */
+int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, float* d_sum_rgb,
+                     void* stream);
+
+/* (1/spp) * sum, then color_to_ppm (src/lib.rs:148-149, :186-192): device
+ * buffers, n_pixels*3 channels. */
+int rt_finalize_device(const rt_scene* scene, const float* d_sum_rgb, size_t n_pixels, uint32_t spp_total,
+                       uint8_t* d_rgb8, void* stream);
+
+/* Host-buffer convenience over the two calls above: sum_rgb (optional) and rgb8
+ * (optional) are HOST arrays of horiz_res*vert_res*3; synchronous. */
+int rt_render(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, float* sum_rgb, uint8_t* rgb8);
+
+/* Nearest hit of n rays: what tree_filter + min_by produce for one segment
+ * (src/boundingvolume.rs:214-231, src/lib.rs:94-98; the linear scan of
+ * src/lib.rs:46-49 when the scene holds discs).  orig/dir: n*3 floats, dir is
+ * used as given.  id[k] = primitive ID or -1; t[k] and normal[3k..] are written
+ * for hits only.  Equal parameters resolve to the lowest ID.  Host buffers. */
+int rt_trace_primary(rt_scene* scene, const float* orig, const float* dir, size_t n, int32_t* id, double* t,
+                     double* normal);
+
+/* Camera rays the render kernel starts from (src/camera.rs:49-78 + src/ray.rs:9-11)
+ * for pixels [pixel_begin, pixel_end) (index j*horiz_res+i) and samples
+ * [sample_begin, sample_end); ray r = (pixel-pixel_begin)*ns + (sample-sample_begin).
+ * Host buffers of n*3 floats. */
+int rt_generate_primary(rt_scene* scene, const rt_camera* cam, uint64_t seed, uint32_t pixel_begin,
+                        uint32_t pixel_end, uint32_t sample_begin, uint32_t sample_end, float* orig, float* dir);
+
+/* Colour of single paths: rgb[3k..] = accel_raytrace of the camera ray of
+ * (pixel[k], sample[k]) (src/lib.rs:88-135).  Host buffers. */
+int rt_trace_paths(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, const uint32_t* pixel,
+                   const uint32_t* sample, size_t n, float* rgb);
+
+/* src/main.rs:35-42 + src/lib.rs:151: "P3\nW H\n255\n" then one "r g b\n" line
+ * per pixel.  Unlike the reference the file is truncated first. */
+int rt_write_ppm(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_MI355X_H */

@@ -1,0 +1,1007 @@
+// rt_device.hip — gfx950 kernels and the device half of the C ABI.
+//
+// Precision policy
+//   * BVH descent runs in f32 on boxes rounded outward, against a ray whose
+//     origin is widened by `eps` on every axis; eps covers every rounding of the
+//     f32 slab arithmetic, so the descent never skips a sphere the f64 test hits.
+//   * The sphere / disc tests and the hit point use the reference's own f64
+//     formulas in the reference's operation order (no FMA contraction), so the
+//     nearest-hit primitive and its parameter equal the f64 restatement's.
+//   * Shading (scatter directions, throughput, sky) runs in f32.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+#include "rt_internal.h"
+
+namespace rt {
+
+#define RT_HIP(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (call);                                                                       \
+        if (e__ != hipSuccess) return fail(RT_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e__)); \
+    } while (0)
+
+constexpr int kBlock = 256;             // threads per workgroup of every kernel here
+constexpr int kLeafSentinel = INT32_MIN;  // "stack empty" marker; leaves are ~k in [-n, -1]
+constexpr int kFuzzMaxAttempts = 16;
+
+struct DiscDev {
+    double cx, cy, cz;
+    double nx, ny, nz;
+    double r;
+    double pad;
+};
+struct TexMatDev {  // orientation of one TextureMap material (src/materials.rs:26-31)
+    float up[3];
+    float a0[3];
+    float a1[3];
+    int32_t tex;
+};
+struct TexImgDev {
+    const uchar4* px;
+    uint32_t w, h;
+};
+
+struct SceneDev {
+    const Node* nodes;
+    const double4* sph;     // leaf order: centre xyz, radius
+    const DiscDev* discs;   // scene order
+    const float4* mat;      // spheres in leaf order, then discs: albedo rgb + (fuzz | refractive index)
+    const int32_t* kind;    // same indexing: material kind | texmat index << 8
+    const int32_t* prim_id; // same indexing: hittable index
+    const TexMatDev* texmat;
+    const TexImgDev* teximg;
+    int32_t n_nodes, n_spheres, n_discs;
+    float eps;              // origin widening for the f32 descent
+};
+
+struct CamDev {
+    float lookfrom[3], lookat[3], h[3], v[3];
+    float aperture, span, inv_w, inv_h;
+    uint32_t W, H;
+};
+
+struct RenderParams {
+    uint32_t sample_begin, sample_end, depth, flags;
+    uint32_t key0, key1;
+    uint32_t n_pixels, tiles_x, tiles_y;
+};
+
+// ---------------------------------------------------------------- Philox
+__device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                               uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = uint64_t(0xD2511F53u) * c0;
+        uint64_t p1 = uint64_t(0xCD9E8D57u) * c2;
+        uint32_t n0 = uint32_t(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n2 = uint32_t(p0 >> 32) ^ c3 ^ k1;
+        c1 = uint32_t(p1);
+        c3 = uint32_t(p0);
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+__device__ __forceinline__ float u01(uint32_t x) { return float(x >> 8) * (1.0f / 16777216.0f); }
+
+// sin/cos of 2*pi*rev (v_sin_f32 / v_cos_f32 take revolutions)
+__device__ __forceinline__ void sincos_rev(float rev, float* s, float* c) {
+    *s = __builtin_amdgcn_sinf(rev);
+    *c = __builtin_amdgcn_cosf(rev);
+}
+// uniform on the unit sphere: same distribution as random_vec3 (src/materials.rs:150-157)
+__device__ __forceinline__ void unit_sphere(float u0, float u1, float* x, float* y, float* z) {
+    float zz = 1.0f - 2.0f * u0;
+    float r = sqrtf(fmaxf(0.0f, 1.0f - zz * zz));
+    float s, c;
+    sincos_rev(u1, &s, &c);
+    *x = r * c;
+    *y = r * s;
+    *z = zz;
+}
+
+// ------------------------------------------------------ f64 shape tests
+// src/geometry.rs:104-121 in the reference's operation order.
+__device__ __forceinline__ bool sphere_intersect_f64(double cx, double cy, double cz, double r, double ox, double oy,
+                                                     double oz, double dx, double dy, double dz, double* t) {
+#pragma clang fp contract(off)
+    double rx = ox - cx, ry = oy - cy, rz = oz - cz;
+    double b = 2.0 * (rx * dx + ry * dy + rz * dz);
+    double c = (rx * rx + ry * ry + rz * rz) - r * r;
+    double discrm = b * b - 4.0 * c;
+    if (discrm < 0.0) return false;
+    double sq = __dsqrt_rn(discrm);
+    double t_smaller = -0.5 * (b + sq);
+    if (t_smaller > 0.0) { *t = t_smaller; return true; }
+    double t_larger = t_smaller + sq;
+    if (t_larger > 1.0e-6) { *t = t_larger; return true; }
+    return false;
+}
+// src/geometry.rs:133-139: no h > 0 test.
+__device__ __forceinline__ bool disc_intersect_f64(const DiscDev& d, double ox, double oy, double oz, double dx,
+                                                   double dy, double dz, double* t) {
+#pragma clang fp contract(off)
+    double nd = d.nx * dx + d.ny * dy + d.nz * dz;
+    if (nd == 0.0) return false;
+    double h = ((d.cx - ox) * d.nx + (d.cy - oy) * d.ny + (d.cz - oz) * d.nz) / nd;
+    double px = (ox + h * dx) - d.cx, py = (oy + h * dy) - d.cy, pz = (oz + h * dz) - d.cz;
+    if (px * px + py * py + pz * pz > d.r * d.r) return false;
+    *t = h;
+    return true;
+}
+// src/boundingvolume.rs:70-95 applied to the sphere's own box [c-r, c+r]
+// (src/boundingvolume.rs:246-248): the LINE test with the 1e-4 divisor.
+__device__ __forceinline__ bool own_box_line_test_f64(double cx, double cy, double cz, double r, double ox, double oy,
+                                                      double oz, double dx, double dy, double dz) {
+#pragma clang fp contract(off)
+    double c[3] = {cx, cy, cz}, o[3] = {ox, oy, oz}, d[3] = {dx, dy, dz};
+    double s[3], e[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double divisor = (d[i] == 0.0) ? 1.0e-4 : d[i];
+        double start = ((c[i] - r) - o[i]) / divisor;
+        double end = ((c[i] + r) - o[i]) / divisor;
+        if (end - start < 0.0) { double tmp = start; start = end; end = tmp; }
+        s[i] = start;
+        e[i] = end;
+    }
+    double st = (s[0] < s[1]) ? s[1] : s[0];
+    double en = (e[0] < e[1]) ? e[0] : e[1];
+    if (st >= en) return false;
+    double st2 = (st < s[2]) ? s[2] : st;
+    double en2 = (en < e[2]) ? en : e[2];
+    return !(st2 >= en2);
+}
+
+// ------------------------------------------------------------ traversal
+struct Best {
+    double t;
+    int32_t k;   // index into mat/kind/prim_id, -1 = none
+    int32_t id;  // hittable index of k (tie rule: lowest wins)
+};
+
+__device__ __forceinline__ void consider(Best& b, double t, int32_t k, int32_t id) {
+    if (b.k < 0 || t < b.t || (t == b.t && id < b.id)) { b.t = t; b.k = k; b.id = id; }
+}
+
+// Nearest hit of one ray.  `stk` points at this lane's column of the LDS stack
+// (entry `level` lives at stk[level * kBlock]).  GATE adds the reference's
+// own-box line test in front of every sphere test (bit-exact candidate set).
+template <bool GATE>
+__device__ __forceinline__ Best closest_hit(const SceneDev& S, double ox, double oy, double oz, float dxf, float dyf,
+                                            float dzf, int32_t* stk) {
+    Best best;
+    best.t = 0.0;
+    best.k = -1;
+    best.id = 0x7fffffff;
+    const double dx = double(dxf), dy = double(dyf), dz = double(dzf);
+
+    // discs first, one by one, with LINE semantics (negative parameters count)
+    for (int32_t i = 0; i < S.n_discs; ++i) {
+        double t;
+        if (disc_intersect_f64(S.discs[i], ox, oy, oz, dx, dy, dz, &t)) consider(best, t, S.n_spheres + i, S.prim_id[S.n_spheres + i]);
+    }
+    if (S.n_nodes == 0) return best;
+    // a sphere parameter is always positive: nothing can beat a non-positive disc hit
+    if (best.k >= 0 && best.t <= 0.0) return best;
+
+    const float of[3] = {float(ox), float(oy), float(oz)};
+    const float df[3] = {dxf, dyf, dzf};
+    float inv[3], A[3], B[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float d = df[a];
+        float i = (fabsf(d) >= 1.0e-18f) ? __frcp_rn(d) : copysignf(1.0e18f, d);
+        inv[a] = i;
+        A[a] = -(of[a] + S.eps) * i;
+        B[a] = -(of[a] - S.eps) * i;
+    }
+    float tmax = 3.0e38f;
+    if (best.k >= 0) tmax = float(best.t) * (1.0f + 4.0e-7f);
+
+    int sp = 0;
+    int32_t node = 0;
+    while (node != kLeafSentinel) {
+        while (node >= 0) {
+            const float4* q = reinterpret_cast<const float4*>(S.nodes + node);
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            // q0 = lo0.xyz hi0.x | q1 = hi0.yz lo1.xy | q2 = lo1.z hi1.xyz | q3 = child0 child1 pad pad
+            float t0x = fmaf(q0.x, inv[0], A[0]), t1x = fmaf(q0.w, inv[0], B[0]);
+            float t0y = fmaf(q0.y, inv[1], A[1]), t1y = fmaf(q1.x, inv[1], B[1]);
+            float t0z = fmaf(q0.z, inv[2], A[2]), t1z = fmaf(q1.y, inv[2], B[2]);
+            float en0 = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
+            float ex0 = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
+            float u0x = fmaf(q1.z, inv[0], A[0]), u1x = fmaf(q2.y, inv[0], B[0]);
+            float u0y = fmaf(q1.w, inv[1], A[1]), u1y = fmaf(q2.z, inv[1], B[1]);
+            float u0z = fmaf(q2.x, inv[2], A[2]), u1z = fmaf(q2.w, inv[2], B[2]);
+            float en1 = fmaxf(fmaxf(fminf(u0x, u1x), fminf(u0y, u1y)), fmaxf(fminf(u0z, u1z), 0.0f));
+            float ex1 = fminf(fminf(fmaxf(u0x, u1x), fmaxf(u0y, u1y)), fminf(fmaxf(u0z, u1z), tmax));
+            const bool h0 = en0 <= ex0, h1 = en1 <= ex1;
+            const int32_t c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+            if (h0 && h1) {
+                const bool swap = en1 < en0;
+                const int32_t near_c = swap ? c1 : c0, far_c = swap ? c0 : c1;
+                stk[sp * kBlock] = far_c;
+                ++sp;
+                node = near_c;
+            } else if (h0) {
+                node = c0;
+            } else if (h1) {
+                node = c1;
+            } else if (sp > 0) {
+                --sp;
+                node = stk[sp * kBlock];
+            } else {
+                node = kLeafSentinel;
+            }
+        }
+        if (node != kLeafSentinel) {
+            const int32_t k = ~node;
+            const double4 s = S.sph[k];
+            double t;
+            bool ok = true;
+            if (GATE) ok = own_box_line_test_f64(s.x, s.y, s.z, s.w, ox, oy, oz, dx, dy, dz);
+            if (ok && sphere_intersect_f64(s.x, s.y, s.z, s.w, ox, oy, oz, dx, dy, dz, &t)) {
+                consider(best, t, k, S.prim_id[k]);
+                tmax = float(best.t) * (1.0f + 4.0e-7f);
+            }
+            if (sp > 0) {
+                --sp;
+                node = stk[sp * kBlock];
+            } else {
+                node = kLeafSentinel;
+            }
+        }
+    }
+    return best;
+}
+
+// ---------------------------------------------------------------- shading
+struct Path {
+    double ox, oy, oz;
+    float dx, dy, dz;
+    float tr, tg, tb;  // throughput ("color" in src/lib.rs:89)
+    uint32_t pixel, sample, bounce;
+};
+
+__device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
+    float inv = rsqrtf(x * x + y * y + z * z);
+    x *= inv; y *= inv; z *= inv;
+}
+
+// src/camera.rs:49-78 + src/ray.rs:9-11 with the two rejection loops replaced
+// by direct draws of the same distributions (quarter disc, unit square).
+__device__ __forceinline__ void camera_ray(const CamDev& C, const RenderParams& P, uint32_t pixel, uint32_t sample,
+                                           float o[3], float d[3]) {
+    const uint4 r = philox4x32_10(pixel, sample, 0u, 0u, P.key0, P.key1);
+    const float rad = sqrtf(u01(r.x));
+    float s, c;
+    sincos_rev(0.25f * u01(r.y), &s, &c);
+    const float la = C.aperture * (rad * c), lb = C.aperture * (rad * s);
+    const uint32_t i = pixel % C.W, j = pixel / C.W;
+    const float gh = (-0.5f + float(i) * C.inv_w) * C.span + u01(r.z) * C.inv_w;
+    const float gv = (0.5f - float(j) * C.inv_h) * C.span + u01(r.w) * C.inv_h;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        o[a] = C.lookfrom[a] + la * C.h[a] + lb * C.v[a];
+        d[a] = (C.lookat[a] + gh * C.h[a] + gv * C.v[a]) - o[a];
+    }
+    normalize3(d[0], d[1], d[2]);
+}
+
+__device__ __forceinline__ void start_path(const CamDev& C, const RenderParams& P, uint32_t pixel, uint32_t sample,
+                                           Path& p) {
+    float o[3], d[3];
+    camera_ray(C, P, pixel, sample, o, d);
+    p.ox = double(o[0]); p.oy = double(o[1]); p.oz = double(o[2]);
+    p.dx = d[0]; p.dy = d[1]; p.dz = d[2];
+    p.tr = p.tg = p.tb = 1.0f;
+    p.pixel = pixel; p.sample = sample; p.bounce = 1;
+}
+
+// src/materials.rs:59-76 + :159-171 + src/lib.rs:194-200
+__device__ __forceinline__ void texture_albedo(const SceneDev& S, int32_t texmat, float lx, float ly, float lz, float* r,
+                                               float* g, float* b) {
+    const TexMatDev& m = S.texmat[texmat];
+    const TexImgDev img = S.teximg[m.tex];
+    const float kPi = 3.14159265358979323846f;
+    float lat = acosf(m.up[0] * lx + m.up[1] * ly + m.up[2] * lz);
+    float lon = atan2f(m.a0[0] * lx + m.a0[1] * ly + m.a0[2] * lz, m.a1[0] * lx + m.a1[1] * ly + m.a1[2] * lz) + kPi;
+    float colf = 0.5f * lon / kPi * float(img.w);
+    float rowf = lat / kPi * float(img.h);
+    // Rust `as u32`: saturating, NaN -> 0
+    uint32_t col = (colf > 0.0f) ? (colf >= 4294967040.0f ? 4294967295u : uint32_t(colf)) : 0u;
+    uint32_t row = (rowf > 0.0f) ? (rowf >= 4294967040.0f ? 4294967295u : uint32_t(rowf)) : 0u;
+    const uchar4 px = img.px[size_t(row % img.h) * img.w + (col % img.w)];
+    *r = float(px.x) / 255.0f;
+    *g = float(px.y) / 255.0f;
+    *b = float(px.z) / 255.0f;
+}
+
+// One segment of accel_raytrace / raytrace (src/lib.rs:93-131).  Returns true
+// when the path goes on; otherwise (Lr,Lg,Lb) is the value the reference returns.
+__device__ __forceinline__ bool advance(const SceneDev& S, const RenderParams& P, Path& p, int32_t* stk, float& Lr,
+                                        float& Lg, float& Lb) {
+    const Best hit = closest_hit<false>(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, stk);
+    if (hit.k < 0) {  // src/lib.rs:117-130
+        const float t = 0.5f * (p.dy + 1.0f);
+        Lr = p.tr * ((1.0f - t) + t * 0.5f);
+        Lg = p.tg * ((1.0f - t) + t * 0.7f);
+        Lb = p.tb * ((1.0f - t) + t * 1.0f);
+        return false;
+    }
+    const int32_t k = hit.k;
+    double hx, hy, hz;  // scatter_loc = orig + t*dir (src/ray.rs:12-14)
+    {
+#pragma clang fp contract(off)
+        hx = p.ox + hit.t * double(p.dx);
+        hy = p.oy + hit.t * double(p.dy);
+        hz = p.oz + hit.t * double(p.dz);
+    }
+    float nx, ny, nz;     // normal_at
+    float lx, ly, lz;     // obj_relative_loc (src/lib.rs:106-113)
+    if (k < S.n_spheres) {
+        const double4 s = S.sph[k];
+        const float rx = float(hx - s.x), ry = float(hy - s.y), rz = float(hz - s.z);
+        const float inv_r = 1.0f / float(s.w);
+        nx = rx * inv_r; ny = ry * inv_r; nz = rz * inv_r;  // src/geometry.rs:123-125
+        lx = rx; ly = ry; lz = rz;
+        normalize3(lx, ly, lz);
+    } else {
+        const DiscDev& dd = S.discs[k - S.n_spheres];
+        nx = float(dd.nx); ny = float(dd.ny); nz = float(dd.nz);  // src/geometry.rs:141-143
+        lx = float(hx - dd.cx); ly = float(hy - dd.cy); lz = float(hz - dd.cz);
+    }
+    const int32_t kind_word = S.kind[k];
+    const int32_t kind = kind_word & 0xff;
+    const float4 m = S.mat[k];
+    const float ddn = p.dx * nx + p.dy * ny + p.dz * nz;
+    if (kind == RT_MAT_EMITTER) {  // src/lib.rs:101-104: the throughput is dropped
+        const float c = fabsf(ddn);
+        Lr = m.x * c; Lg = m.y * c; Lb = m.z * c;
+        return false;
+    }
+    float sx, sy, sz;  // scattered direction before Ray::new normalises it
+    float ar = m.x, ag = m.y, ab = m.z;
+    if (kind == RT_MAT_DIFFUSE || kind == RT_MAT_TEXTUREMAP) {  // src/materials.rs:82-85, :122-125
+        const uint4 r = philox4x32_10(p.pixel, p.sample, p.bounce, 0u, P.key0, P.key1);
+        float vx, vy, vz;
+        unit_sphere(u01(r.x), u01(r.y), &vx, &vy, &vz);
+        sx = nx + vx; sy = ny + vy; sz = nz + vz;
+        if (kind == RT_MAT_TEXTUREMAP) texture_albedo(S, kind_word >> 8, lx, ly, lz, &ar, &ag, &ab);
+    } else if (kind == RT_MAT_METAL) {  // src/materials.rs:86-95, fuzzify :141-148
+        const float rx = p.dx - 2.0f * ddn * nx, ry = p.dy - 2.0f * ddn * ny, rz = p.dz - 2.0f * ddn * nz;
+        bool accepted = false;
+        sx = rx; sy = ry; sz = rz;
+        for (uint32_t attempt = 0; attempt < uint32_t(kFuzzMaxAttempts); ++attempt) {
+            const uint4 r = philox4x32_10(p.pixel, p.sample, p.bounce, attempt, P.key0, P.key1);
+            float vx, vy, vz;
+            unit_sphere(u01(r.x), u01(r.y), &vx, &vy, &vz);
+            sx = rx + m.w * vx; sy = ry + m.w * vy; sz = rz + m.w * vz;
+            if (sx * nx + sy * ny + sz * nz > 0.0f) { accepted = true; break; }
+        }
+        if (!accepted) {  // the reference would recurse without bound here
+            Lr = Lg = Lb = 0.0f;
+            return false;
+        }
+    } else {  // RT_MAT_DIELECTRIC, src/materials.rs:96-121
+        const float inc_cos = ddn;
+        const float px = p.dx - inc_cos * nx, py = p.dy - inc_cos * ny, pz = p.dz - inc_cos * nz;
+        const bool entering = __float_as_uint(inc_cos) >> 31;  // signum < 0 (also for -0.0)
+        const float ratio = entering ? 1.0f / m.w : m.w;
+        const float qx = ratio * px, qy = ratio * py, qz = ratio * pz;
+        const float sin2 = qx * qx + qy * qy + qz * qz;
+        bool reflect = sin2 > 1.0f;
+        if (!reflect) {  // the Schlick draw happens only when sin2 <= 1 (`||` short-circuits)
+            const uint4 r = philox4x32_10(p.pixel, p.sample, p.bounce, 0u, P.key0, P.key1);
+            float r0 = (1.0f - ratio) / (1.0f + ratio);
+            r0 = r0 * r0;
+            const float x = 1.0f - fabsf(inc_cos);
+            const float reflectance = r0 + (1.0f - r0) * (x * x * x * x * x);
+            reflect = u01(r.z) < reflectance;
+        }
+        if (reflect) {
+            sx = px - inc_cos * nx; sy = py - inc_cos * ny; sz = pz - inc_cos * nz;
+        } else {
+            const float sc_cos = (entering ? -1.0f : 1.0f) * sqrtf(1.0f - sin2);
+            sx = qx + sc_cos * nx; sy = qy + sc_cos * ny; sz = qz + sc_cos * nz;
+        }
+        ar = ag = ab = 1.0f;  // src/materials.rs:56-58
+    }
+    normalize3(sx, sy, sz);  // Ray::new
+    p.tr *= ar; p.tg *= ag; p.tb *= ab;
+    p.ox = hx; p.oy = hy; p.oz = hz;
+    p.dx = sx; p.dy = sy; p.dz = sz;
+    if (p.bounce >= P.depth) {  // src/lib.rs:134: depth exhausted returns the throughput
+        Lr = p.tr; Lg = p.tg; Lb = p.tb;
+        return false;
+    }
+    ++p.bounce;
+    return true;
+}
+
+// ---------------------------------------------------------------- kernels
+// Persistent render kernel.  A lane owns one pixel at a time and walks its
+// samples in order, so a pixel's sum is formed in sample order by one lane: no
+// atomics on the image and bit-reproducible output.  A lane whose path ends
+// starts the pixel's next sample at once; a lane whose pixel is finished draws
+// the next pixel index from a global counter.
+__global__ __launch_bounds__(kBlock) void render_kernel(SceneDev S, CamDev C, RenderParams P, float* __restrict__ sum_rgb,
+                                                        uint32_t* __restrict__ work_counter) {
+    extern __shared__ int32_t stack_lds[];
+    int32_t* stk = stack_lds + threadIdx.x;
+
+    Path p;
+    p.ox = p.oy = p.oz = 0.0;
+    p.dx = p.dy = p.dz = 0.0f;
+    p.tr = p.tg = p.tb = 0.0f;
+    p.pixel = 0; p.sample = 0; p.bounce = 0;
+    bool have_pixel = false, alive = false, done = false;
+    uint32_t next_sample = 0;
+    float ar = 0.0f, ag = 0.0f, ab = 0.0f;
+    const uint32_t n_work = P.tiles_x * P.tiles_y * 64u;
+
+    for (;;) {
+        if (!alive && !done) {
+            if (have_pixel && next_sample >= P.sample_end) {  // pixel finished: write its sum
+                float* out = sum_rgb + 3 * size_t(p.pixel);
+                if (P.flags & RT_RENDER_ACCUMULATE) { ar += out[0]; ag += out[1]; ab += out[2]; }
+                out[0] = ar; out[1] = ag; out[2] = ab;
+                have_pixel = false;
+            }
+            if (!have_pixel) {
+                const uint32_t w = atomicAdd(work_counter, 1u);
+                if (w >= n_work) {
+                    done = true;
+                } else {
+                    // work index -> pixel: 8x8 tiles, row-major inside the tile
+                    const uint32_t tile = w >> 6, in_tile = w & 63u;
+                    const uint32_t x = (tile % P.tiles_x) * 8u + (in_tile & 7u);
+                    const uint32_t y = (tile / P.tiles_x) * 8u + (in_tile >> 3);
+                    if (x < C.W && y < C.H) {
+                        have_pixel = true;
+                        p.pixel = y * C.W + x;
+                        next_sample = P.sample_begin;
+                        ar = ag = ab = 0.0f;
+                    }
+                }
+            }
+            if (have_pixel && next_sample < P.sample_end) {
+                if (P.depth == 0) {  // `for _ in 1..=0` never runs: the colour is the initial throughput
+                    ar += 1.0f; ag += 1.0f; ab += 1.0f;
+                } else {
+                    start_path(C, P, p.pixel, next_sample, p);
+                    alive = true;
+                }
+                ++next_sample;
+            }
+        }
+        if (__all(done)) break;
+        if (alive) {
+            float Lr, Lg, Lb;
+            if (!advance(S, P, p, stk, Lr, Lg, Lb)) {
+                ar += Lr; ag += Lg; ab += Lb;
+                alive = false;
+            }
+        }
+    }
+}
+
+// One thread per listed path: the colour accel_raytrace returns for it.
+__global__ __launch_bounds__(kBlock) void trace_paths_kernel(SceneDev S, CamDev C, RenderParams P,
+                                                             const uint32_t* __restrict__ pixel,
+                                                             const uint32_t* __restrict__ sample, uint32_t n,
+                                                             float* __restrict__ rgb) {
+    extern __shared__ int32_t stack_lds[];
+    int32_t* stk = stack_lds + threadIdx.x;
+    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
+    if (g >= n) return;
+    float Lr = 1.0f, Lg = 1.0f, Lb = 1.0f;
+    if (P.depth > 0) {
+        Path p;
+        start_path(C, P, pixel[g], sample[g], p);
+        while (advance(S, P, p, stk, Lr, Lg, Lb)) {}
+    }
+    rgb[3 * size_t(g)] = Lr; rgb[3 * size_t(g) + 1] = Lg; rgb[3 * size_t(g) + 2] = Lb;
+}
+
+__global__ __launch_bounds__(kBlock) void generate_primary_kernel(CamDev C, RenderParams P, uint32_t pixel_begin,
+                                                                  uint32_t ns, uint32_t n, float* __restrict__ orig,
+                                                                  float* __restrict__ dir) {
+    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
+    if (g >= n) return;
+    float o[3], d[3];
+    camera_ray(C, P, pixel_begin + g / ns, P.sample_begin + g % ns, o, d);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { orig[3 * size_t(g) + a] = o[a]; dir[3 * size_t(g) + a] = d[a]; }
+}
+
+__global__ __launch_bounds__(kBlock) void trace_primary_kernel(SceneDev S, const float* __restrict__ orig,
+                                                               const float* __restrict__ dir, uint32_t n,
+                                                               int32_t* __restrict__ id, double* __restrict__ t,
+                                                               double* __restrict__ normal) {
+    extern __shared__ int32_t stack_lds[];
+    int32_t* stk = stack_lds + threadIdx.x;
+    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
+    if (g >= n) return;
+    const double ox = double(orig[3 * size_t(g)]), oy = double(orig[3 * size_t(g) + 1]), oz = double(orig[3 * size_t(g) + 2]);
+    const float dx = dir[3 * size_t(g)], dy = dir[3 * size_t(g) + 1], dz = dir[3 * size_t(g) + 2];
+    const Best hit = closest_hit<true>(S, ox, oy, oz, dx, dy, dz, stk);
+    if (hit.k < 0) { id[g] = -1; return; }
+    id[g] = hit.id;
+    t[g] = hit.t;
+    double nx, ny, nz;
+    if (hit.k < S.n_spheres) {
+#pragma clang fp contract(off)
+        const double4 s = S.sph[hit.k];
+        nx = ((ox + hit.t * double(dx)) - s.x) / s.w;  // src/geometry.rs:123-125 at src/ray.rs:12-14
+        ny = ((oy + hit.t * double(dy)) - s.y) / s.w;
+        nz = ((oz + hit.t * double(dz)) - s.z) / s.w;
+    } else {
+        const DiscDev& dd = S.discs[hit.k - S.n_spheres];
+        nx = dd.nx; ny = dd.ny; nz = dd.nz;
+    }
+    normal[3 * size_t(g)] = nx; normal[3 * size_t(g) + 1] = ny; normal[3 * size_t(g) + 2] = nz;
+}
+
+// (1/spp)*sum then color_to_ppm (src/lib.rs:148-149, :186-192), in f64 like the reference.
+__global__ __launch_bounds__(kBlock) void finalize_kernel(const float* __restrict__ sum_rgb, size_t n_channels,
+                                                          double inv_spp, uint8_t* __restrict__ rgb8) {
+    const size_t g = size_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (g >= n_channels) return;
+    const double x = 255.0 * __dsqrt_rn(inv_spp * double(sum_rgb[g]));
+    uint8_t q = 0;  // Rust `as u8`: NaN -> 0, saturating, truncating
+    if (x > 0.0) q = (x >= 255.0) ? uint8_t(255) : uint8_t(int(x));
+    rgb8[g] = q;
+}
+
+}  // namespace rt
+
+// =====================================================================
+// host side of the device ABI
+// =====================================================================
+using namespace rt;
+
+struct rt_scene {
+    int device = 0;
+    rt_scene_info info{};
+    std::vector<rt_hittable> hittables;
+    SceneDev dev{};
+    std::vector<void*> allocations;
+    uint32_t* d_work_counter = nullptr;
+    uint32_t stack_depth = 0;
+    int n_cu = 0;
+    double bound_abs = 0.0;  // largest |coordinate| of any box corner
+};
+
+namespace {
+
+template <class T>
+int upload(rt_scene* sc, const std::vector<T>& host, const T** dev_ptr) {
+    *dev_ptr = nullptr;
+    if (host.empty()) return RT_OK;
+    void* p = nullptr;
+    RT_HIP(hipMalloc(&p, host.size() * sizeof(T)));
+    sc->allocations.push_back(p);
+    sc->info.device_bytes += host.size() * sizeof(T);
+    RT_HIP(hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dev_ptr = static_cast<const T*>(p);
+    return RT_OK;
+}
+
+void normalize3d(double v[3]) {
+    double n = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    for (int i = 0; i < 3; ++i) v[i] = v[i] / n;
+}
+
+CamDev make_cam(const rt_camera& c) {
+    CamDev d;
+    for (int a = 0; a < 3; ++a) {
+        d.lookfrom[a] = float(c.lookfrom[a]);
+        d.lookat[a] = float(c.lookat[a]);
+        d.h[a] = float(c.horiz_arm[a]);
+        d.v[a] = float(c.vert_arm[a]);
+    }
+    d.aperture = float(c.aperture);
+    d.span = float(c.inv_focal_length * c.focal_distance);  // src/camera.rs:67-68
+    d.inv_w = float(1.0 / double(c.horiz_res));
+    d.inv_h = float(1.0 / double(c.vert_res));
+    d.W = c.horiz_res;
+    d.H = c.vert_res;
+    return d;
+}
+
+// eps for a batch of rays whose origins stay within `origin_abs` of zero
+float descent_eps(const rt_scene* sc, double origin_abs) {
+    double extent = 2.0 * std::max(sc->bound_abs, origin_abs);
+    return float(extent * (1.0 / 2097152.0));  // 2^-21 of the largest distance between a box plane and an origin
+}
+
+size_t stack_bytes(const rt_scene* sc) { return size_t(std::max<uint32_t>(sc->stack_depth, 1u)) * kBlock * sizeof(int32_t); }
+
+int check_render_args(const rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, const char* who) {
+    if (!scene || !cam || !opts) return fail(RT_ERR_INVALID_ARGUMENT, "%s: null argument", who);
+    if (cam->horiz_res == 0 || cam->vert_res == 0) return fail(RT_ERR_INVALID_ARGUMENT, "%s: zero resolution", who);
+    if (uint64_t(cam->horiz_res) * cam->vert_res > 0x7fffffffull / 64)
+        return fail(RT_ERR_LIMIT, "%s: more than 2^25 pixels", who);
+    if (opts->sample_end <= opts->sample_begin)
+        return fail(RT_ERR_INVALID_ARGUMENT, "%s: empty sample range [%u, %u)", who, opts->sample_begin, opts->sample_end);
+    return RT_OK;
+}
+
+RenderParams make_params(const rt_camera& cam, const rt_render_opts& o) {
+    RenderParams P;
+    P.sample_begin = o.sample_begin;
+    P.sample_end = o.sample_end;
+    P.depth = o.depth;
+    P.flags = o.flags;
+    P.key0 = uint32_t(o.seed);
+    P.key1 = uint32_t(o.seed >> 32);
+    P.n_pixels = cam.horiz_res * cam.vert_res;
+    P.tiles_x = (cam.horiz_res + 7) / 8;
+    P.tiles_y = (cam.vert_res + 7) / 8;
+    return P;
+}
+
+double camera_abs(const rt_camera& c) {
+    double m = 0.0;
+    for (int a = 0; a < 3; ++a) m = std::max(m, std::fabs(c.lookfrom[a]) + std::fabs(c.aperture));
+    return m;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void rt_scene_destroy(rt_scene* scene) {
+    if (!scene) return;
+    (void)hipSetDevice(scene->device);
+    for (void* p : scene->allocations) (void)hipFree(p);
+    delete scene;
+}
+
+int rt_scene_create(const rt_hittable* hittables, size_t n_hittables, const rt_texture* textures, size_t n_textures,
+                    int device, rt_scene** out) {
+    if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: null out pointer");
+    *out = nullptr;
+    if (!hittables && n_hittables) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: null hittables");
+    if (!textures && n_textures) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: null textures");
+    if (n_hittables > (size_t(1) << 30)) return fail(RT_ERR_LIMIT, "rt_scene_create: more than 2^30 hittables");
+    int n_dev = rt_device_count();
+    if (n_dev <= 0) return fail(RT_ERR_DEVICE, "rt_scene_create: no HIP device is visible");
+    if (device < 0 || device >= n_dev) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: device %d of %d", device, n_dev);
+    auto t0 = std::chrono::steady_clock::now();
+
+    // validate and split by shape
+    std::vector<uint32_t> sphere_ids, disc_ids;
+    for (size_t i = 0; i < n_hittables; ++i) {
+        const rt_hittable& h = hittables[i];
+        if (h.shape == RT_SHAPE_SPHERE) sphere_ids.push_back(uint32_t(i));
+        else if (h.shape == RT_SHAPE_DISC) disc_ids.push_back(uint32_t(i));
+        else return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: hittable %zu has shape %d", i, h.shape);
+        if (h.material < RT_MAT_DIFFUSE || h.material > RT_MAT_EMITTER)
+            return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: hittable %zu has material %d", i, h.material);
+        if (h.material == RT_MAT_TEXTUREMAP && (h.texture < 0 || size_t(h.texture) >= n_textures))
+            return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: hittable %zu names texture %d of %zu", i, h.texture, n_textures);
+    }
+    for (size_t i = 0; i < n_textures; ++i)
+        if (!textures[i].rgb8 || textures[i].width == 0 || textures[i].height == 0)
+            return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: texture %zu is empty", i);
+
+    rt_scene* sc = new rt_scene;
+    sc->device = device;
+    sc->hittables.assign(hittables, hittables + n_hittables);
+    auto bail = [&](int code) { rt_scene_destroy(sc); return code; };
+    if (hipSetDevice(device) != hipSuccess) return bail(fail(RT_ERR_DEVICE, "rt_scene_create: hipSetDevice(%d) failed", device));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return bail(fail(RT_ERR_DEVICE, "rt_scene_create: hipGetDeviceProperties failed"));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return bail(fail(RT_ERR_DEVICE, "rt_scene_create: device %d is %s, this library is built for gfx950 only", device, prop.gcnArchName));
+    sc->n_cu = prop.multiProcessorCount;
+
+    // BVH over the spheres
+    std::vector<double> sph4(4 * sphere_ids.size());
+    for (size_t i = 0; i < sphere_ids.size(); ++i) {
+        const rt_hittable& h = hittables[sphere_ids[i]];
+        sph4[4 * i] = h.centre[0]; sph4[4 * i + 1] = h.centre[1]; sph4[4 * i + 2] = h.centre[2]; sph4[4 * i + 3] = h.radius;
+    }
+    uint32_t lg = 0;
+    while ((size_t(1) << lg) < sphere_ids.size()) ++lg;
+    BuiltBvh bvh;
+    build_bvh(sph4.data(), sphere_ids.size(), lg + 7, &bvh);
+    sc->stack_depth = bvh.depth + 1;
+    double bound = 0.0;
+    for (int a = 0; a < 3; ++a) bound = std::max(bound, std::max(std::fabs(bvh.scene_lo[a]), std::fabs(bvh.scene_hi[a])));
+
+    // SoA primitive tables: spheres in leaf order, then discs in scene order
+    const size_t n_s = sphere_ids.size(), n_d = disc_ids.size();
+    std::vector<double4> h_sph(n_s);
+    std::vector<DiscDev> h_disc(n_d);
+    std::vector<float4> h_mat(n_s + n_d);
+    std::vector<int32_t> h_kind(n_s + n_d), h_id(n_s + n_d);
+    std::vector<TexMatDev> h_texmat;
+    auto fill_material = [&](size_t k, uint32_t id) {
+        const rt_hittable& h = hittables[id];
+        float w = 0.0f;
+        if (h.material == RT_MAT_METAL) w = float(h.fuzz);
+        if (h.material == RT_MAT_DIELECTRIC) w = float(h.refractive_index);
+        h_mat[k] = make_float4(float(h.albedo[0]), float(h.albedo[1]), float(h.albedo[2]), w);
+        int32_t word = h.material;
+        if (h.material == RT_MAT_TEXTUREMAP) {
+            TexMatDev tm;
+            double up[3] = {h.orient_up[0], h.orient_up[1], h.orient_up[2]};
+            double ar[3] = {h.orient_around[0], h.orient_around[1], h.orient_around[2]};
+            normalize3d(up);  // src/materials.rs:64-68: both are normalised, the pair is NOT re-orthogonalised
+            normalize3d(ar);
+            double a1[3] = {up[1] * ar[2] - up[2] * ar[1], up[2] * ar[0] - up[0] * ar[2], up[0] * ar[1] - up[1] * ar[0]};
+            for (int a = 0; a < 3; ++a) { tm.up[a] = float(up[a]); tm.a0[a] = float(ar[a]); tm.a1[a] = float(a1[a]); }
+            tm.tex = h.texture;
+            word |= int32_t(h_texmat.size()) << 8;
+            h_texmat.push_back(tm);
+        }
+        h_kind[k] = word;
+        h_id[k] = int32_t(id);
+    };
+    for (size_t k = 0; k < n_s; ++k) {
+        const uint32_t id = sphere_ids[bvh.leaf_order[k]];
+        const rt_hittable& h = hittables[id];
+        h_sph[k] = make_double4(h.centre[0], h.centre[1], h.centre[2], h.radius);
+        fill_material(k, id);
+    }
+    for (size_t i = 0; i < n_d; ++i) {
+        const rt_hittable& h = hittables[disc_ids[i]];
+        DiscDev d;
+        d.cx = h.centre[0]; d.cy = h.centre[1]; d.cz = h.centre[2];
+        d.nx = h.normal[0]; d.ny = h.normal[1]; d.nz = h.normal[2];
+        d.r = h.radius; d.pad = 0.0;
+        h_disc[i] = d;
+        for (int a = 0; a < 3; ++a) bound = std::max(bound, std::fabs(h.centre[a]) + std::fabs(h.radius));
+        fill_material(n_s + i, disc_ids[i]);
+    }
+    sc->bound_abs = bound;
+
+    // textures as RGBA8 so one texel is one aligned 4-byte load
+    std::vector<TexImgDev> h_teximg(n_textures);
+    for (size_t i = 0; i < n_textures; ++i) {
+        const size_t n_px = size_t(textures[i].width) * textures[i].height;
+        std::vector<uchar4> rgba(n_px);
+        for (size_t p = 0; p < n_px; ++p)
+            rgba[p] = make_uchar4(textures[i].rgb8[3 * p], textures[i].rgb8[3 * p + 1], textures[i].rgb8[3 * p + 2], 255);
+        const uchar4* d_px = nullptr;
+        int rc = upload(sc, rgba, &d_px);
+        if (rc != RT_OK) return bail(rc);
+        h_teximg[i] = TexImgDev{d_px, textures[i].width, textures[i].height};
+    }
+
+    int rc;
+    if ((rc = upload(sc, bvh.nodes, &sc->dev.nodes)) != RT_OK) return bail(rc);
+    if ((rc = upload(sc, h_sph, &sc->dev.sph)) != RT_OK) return bail(rc);
+    if ((rc = upload(sc, h_disc, &sc->dev.discs)) != RT_OK) return bail(rc);
+    if ((rc = upload(sc, h_mat, &sc->dev.mat)) != RT_OK) return bail(rc);
+    if ((rc = upload(sc, h_kind, &sc->dev.kind)) != RT_OK) return bail(rc);
+    if ((rc = upload(sc, h_id, &sc->dev.prim_id)) != RT_OK) return bail(rc);
+    if ((rc = upload(sc, h_texmat, &sc->dev.texmat)) != RT_OK) return bail(rc);
+    if ((rc = upload(sc, h_teximg, &sc->dev.teximg)) != RT_OK) return bail(rc);
+    sc->dev.n_nodes = int32_t(bvh.nodes.size());
+    sc->dev.n_spheres = int32_t(n_s);
+    sc->dev.n_discs = int32_t(n_d);
+    sc->dev.eps = 0.0f;
+    {
+        void* p = nullptr;
+        if (hipMalloc(&p, 256) != hipSuccess) return bail(fail(RT_ERR_DEVICE, "rt_scene_create: hipMalloc of the work counter failed"));
+        sc->allocations.push_back(p);
+        sc->d_work_counter = static_cast<uint32_t*>(p);
+    }
+    if (stack_bytes(sc) > 64 * 1024)
+        return bail(fail(RT_ERR_LIMIT, "rt_scene_create: BVH depth %u needs a %zu-byte LDS stack", bvh.depth, stack_bytes(sc)));
+
+    sc->info.n_hittables = n_hittables;
+    sc->info.n_spheres = n_s;
+    sc->info.n_discs = n_d;
+    sc->info.n_nodes = bvh.nodes.size();
+    sc->info.bvh_depth = bvh.depth;
+    sc->info.stack_depth = sc->stack_depth;
+    sc->info.device = device;
+    sc->info.lds_resident = 0;
+    sc->info.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    *out = sc;
+    return RT_OK;
+}
+
+int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out) {
+    if (!scene || !out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_get_info: null argument");
+    *out = scene->info;
+    return RT_OK;
+}
+
+int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, float* d_sum_rgb, void* stream) {
+    int rc = check_render_args(scene, cam, opts, "rt_render_device");
+    if (rc != RT_OK) return rc;
+    if (!d_sum_rgb) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_device: null output buffer");
+    RT_HIP(hipSetDevice(scene->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    SceneDev S = scene->dev;
+    S.eps = descent_eps(scene, camera_abs(*cam));
+    const CamDev C = make_cam(*cam);
+    const RenderParams P = make_params(*cam, *opts);
+    const size_t lds = stack_bytes(scene);
+    int per_cu = 0;
+    RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel, kBlock, lds));
+    if (per_cu < 1) per_cu = 1;
+    const uint64_t n_work = uint64_t(P.tiles_x) * P.tiles_y * 64u;
+    uint64_t blocks = uint64_t(scene->n_cu) * uint64_t(per_cu);
+    blocks = std::min<uint64_t>(blocks, (n_work + kBlock - 1) / kBlock);
+    RT_HIP(hipMemsetAsync(scene->d_work_counter, 0, sizeof(uint32_t), st));
+    hipLaunchKernelGGL(render_kernel, dim3(uint32_t(blocks)), dim3(kBlock), lds, st, S, C, P, d_sum_rgb, scene->d_work_counter);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_finalize_device(const rt_scene* scene, const float* d_sum_rgb, size_t n_pixels, uint32_t spp_total, uint8_t* d_rgb8,
+                       void* stream) {
+    if (!scene || !d_sum_rgb || !d_rgb8) return fail(RT_ERR_INVALID_ARGUMENT, "rt_finalize_device: null argument");
+    if (spp_total == 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_finalize_device: spp_total is zero");
+    RT_HIP(hipSetDevice(scene->device));
+    const size_t n = n_pixels * 3;
+    if (n == 0) return RT_OK;
+    hipLaunchKernelGGL(finalize_kernel, dim3(uint32_t((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), d_sum_rgb, n, 1.0 / double(spp_total), d_rgb8);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_render(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, float* sum_rgb, uint8_t* rgb8) {
+    int rc = check_render_args(scene, cam, opts, "rt_render");
+    if (rc != RT_OK) return rc;
+    RT_HIP(hipSetDevice(scene->device));
+    const size_t n_pixels = size_t(cam->horiz_res) * cam->vert_res;
+    float* d_sum = nullptr;
+    uint8_t* d_rgb = nullptr;
+    RT_HIP(hipMalloc(reinterpret_cast<void**>(&d_sum), n_pixels * 3 * sizeof(float)));
+    auto cleanup = [&]() { (void)hipFree(d_sum); if (d_rgb) (void)hipFree(d_rgb); };
+    if ((opts->flags & RT_RENDER_ACCUMULATE) && sum_rgb) {
+        if (hipMemcpy(d_sum, sum_rgb, n_pixels * 3 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return fail(RT_ERR_DEVICE, "rt_render: upload of the running sum failed"); }
+    } else if (opts->flags & RT_RENDER_ACCUMULATE) {
+        cleanup();
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: RT_RENDER_ACCUMULATE needs sum_rgb");
+    }
+    rc = rt_render_device(scene, cam, opts, d_sum, nullptr);
+    if (rc == RT_OK && rgb8) {
+        if (hipMalloc(reinterpret_cast<void**>(&d_rgb), n_pixels * 3) != hipSuccess) { cleanup(); return fail(RT_ERR_DEVICE, "rt_render: hipMalloc failed"); }
+        rc = rt_finalize_device(scene, d_sum, n_pixels, opts->sample_end - opts->sample_begin, d_rgb, nullptr);
+    }
+    if (rc == RT_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(RT_ERR_DEVICE, "rt_render: kernel execution failed: %s", hipGetErrorString(hipGetLastError()));
+    if (rc == RT_OK && sum_rgb && hipMemcpy(sum_rgb, d_sum, n_pixels * 3 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(RT_ERR_DEVICE, "rt_render: download failed");
+    if (rc == RT_OK && rgb8 && hipMemcpy(rgb8, d_rgb, n_pixels * 3, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(RT_ERR_DEVICE, "rt_render: download failed");
+    cleanup();
+    return rc;
+}
+
+int rt_trace_primary(rt_scene* scene, const float* orig, const float* dir, size_t n, int32_t* id, double* t, double* normal) {
+    if (!scene || !orig || !dir || !id || !t || !normal) return fail(RT_ERR_INVALID_ARGUMENT, "rt_trace_primary: null argument");
+    if (n == 0) return RT_OK;
+    if (n > 0x7fffffffull - kBlock) return fail(RT_ERR_LIMIT, "rt_trace_primary: more than 2^31 rays in one call");
+    RT_HIP(hipSetDevice(scene->device));
+    double origin_abs = 0.0;
+    for (size_t i = 0; i < 3 * n; ++i) {
+        if (!std::isfinite(orig[i]) || !std::isfinite(dir[i])) return fail(RT_ERR_INVALID_ARGUMENT, "rt_trace_primary: non-finite ray component at %zu", i);
+        origin_abs = std::max(origin_abs, double(std::fabs(orig[i])));
+    }
+    float *d_o = nullptr, *d_d = nullptr;
+    int32_t* d_id = nullptr;
+    double *d_t = nullptr, *d_n = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_id); (void)hipFree(d_t); (void)hipFree(d_n); };
+    int rc = RT_OK;
+    auto chk = [&](hipError_t e, const char* what) { if (e != hipSuccess && rc == RT_OK) rc = fail(RT_ERR_DEVICE, "rt_trace_primary: %s failed: %s", what, hipGetErrorString(e)); };
+    chk(hipMalloc(reinterpret_cast<void**>(&d_o), 3 * n * sizeof(float)), "hipMalloc");
+    chk(hipMalloc(reinterpret_cast<void**>(&d_d), 3 * n * sizeof(float)), "hipMalloc");
+    chk(hipMalloc(reinterpret_cast<void**>(&d_id), n * sizeof(int32_t)), "hipMalloc");
+    chk(hipMalloc(reinterpret_cast<void**>(&d_t), n * sizeof(double)), "hipMalloc");
+    chk(hipMalloc(reinterpret_cast<void**>(&d_n), 3 * n * sizeof(double)), "hipMalloc");
+    if (rc == RT_OK) {
+        chk(hipMemcpy(d_o, orig, 3 * n * sizeof(float), hipMemcpyHostToDevice), "upload");
+        chk(hipMemcpy(d_d, dir, 3 * n * sizeof(float), hipMemcpyHostToDevice), "upload");
+        chk(hipMemset(d_t, 0, n * sizeof(double)), "memset");
+        chk(hipMemset(d_n, 0, 3 * n * sizeof(double)), "memset");
+    }
+    if (rc == RT_OK) {
+        SceneDev S = scene->dev;
+        S.eps = descent_eps(scene, origin_abs);
+        hipLaunchKernelGGL(trace_primary_kernel, dim3(uint32_t((n + kBlock - 1) / kBlock)), dim3(kBlock), stack_bytes(scene), nullptr,
+                           S, d_o, d_d, uint32_t(n), d_id, d_t, d_n);
+        chk(hipGetLastError(), "launch");
+        chk(hipDeviceSynchronize(), "kernel");
+    }
+    if (rc == RT_OK) {
+        chk(hipMemcpy(id, d_id, n * sizeof(int32_t), hipMemcpyDeviceToHost), "download");
+        std::vector<double> ht(n), hn(3 * n);
+        chk(hipMemcpy(ht.data(), d_t, n * sizeof(double), hipMemcpyDeviceToHost), "download");
+        chk(hipMemcpy(hn.data(), d_n, 3 * n * sizeof(double), hipMemcpyDeviceToHost), "download");
+        if (rc == RT_OK)
+            for (size_t k = 0; k < n; ++k)
+                if (id[k] >= 0) { t[k] = ht[k]; for (int a = 0; a < 3; ++a) normal[3 * k + a] = hn[3 * k + a]; }
+    }
+    cleanup();
+    return rc;
+}
+
+int rt_generate_primary(rt_scene* scene, const rt_camera* cam, uint64_t seed, uint32_t pixel_begin, uint32_t pixel_end,
+                        uint32_t sample_begin, uint32_t sample_end, float* orig, float* dir) {
+    if (!scene || !cam || !orig || !dir) return fail(RT_ERR_INVALID_ARGUMENT, "rt_generate_primary: null argument");
+    if (cam->horiz_res == 0 || cam->vert_res == 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_generate_primary: zero resolution");
+    if (pixel_end < pixel_begin || uint64_t(pixel_end) > uint64_t(cam->horiz_res) * cam->vert_res || sample_end <= sample_begin)
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_generate_primary: bad pixel or sample range");
+    const uint64_t ns = sample_end - sample_begin, n = uint64_t(pixel_end - pixel_begin) * ns;
+    if (n == 0) return RT_OK;
+    if (n > 0x7fffffffull - kBlock) return fail(RT_ERR_LIMIT, "rt_generate_primary: more than 2^31 rays in one call");
+    RT_HIP(hipSetDevice(scene->device));
+    float *d_o = nullptr, *d_d = nullptr;
+    RT_HIP(hipMalloc(reinterpret_cast<void**>(&d_o), 3 * n * sizeof(float)));
+    if (hipMalloc(reinterpret_cast<void**>(&d_d), 3 * n * sizeof(float)) != hipSuccess) { (void)hipFree(d_o); return fail(RT_ERR_DEVICE, "rt_generate_primary: hipMalloc failed"); }
+    rt_render_opts o{};
+    o.sample_begin = sample_begin; o.sample_end = sample_end; o.depth = 1; o.flags = 0; o.seed = seed;
+    const RenderParams P = make_params(*cam, o);
+    hipLaunchKernelGGL(generate_primary_kernel, dim3(uint32_t((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr, make_cam(*cam), P,
+                       pixel_begin, uint32_t(ns), uint32_t(n), d_o, d_d);
+    int rc = RT_OK;
+    if (hipDeviceSynchronize() != hipSuccess) rc = fail(RT_ERR_DEVICE, "rt_generate_primary: kernel failed");
+    if (rc == RT_OK && (hipMemcpy(orig, d_o, 3 * n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
+                        hipMemcpy(dir, d_d, 3 * n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess))
+        rc = fail(RT_ERR_DEVICE, "rt_generate_primary: download failed");
+    (void)hipFree(d_o);
+    (void)hipFree(d_d);
+    return rc;
+}
+
+int rt_trace_paths(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, const uint32_t* pixel,
+                   const uint32_t* sample, size_t n, float* rgb) {
+    if (!scene || !cam || !opts || !pixel || !sample || !rgb) return fail(RT_ERR_INVALID_ARGUMENT, "rt_trace_paths: null argument");
+    if (cam->horiz_res == 0 || cam->vert_res == 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_trace_paths: zero resolution");
+    if (n == 0) return RT_OK;
+    if (n > 0x7fffffffull - kBlock) return fail(RT_ERR_LIMIT, "rt_trace_paths: more than 2^31 paths in one call");
+    const uint64_t n_pixels = uint64_t(cam->horiz_res) * cam->vert_res;
+    for (size_t k = 0; k < n; ++k)
+        if (pixel[k] >= n_pixels) return fail(RT_ERR_INVALID_ARGUMENT, "rt_trace_paths: pixel %u of %llu", pixel[k], (unsigned long long)n_pixels);
+    RT_HIP(hipSetDevice(scene->device));
+    uint32_t *d_p = nullptr, *d_s = nullptr;
+    float* d_rgb = nullptr;
+    int rc = RT_OK;
+    auto chk = [&](hipError_t e, const char* what) { if (e != hipSuccess && rc == RT_OK) rc = fail(RT_ERR_DEVICE, "rt_trace_paths: %s failed: %s", what, hipGetErrorString(e)); };
+    chk(hipMalloc(reinterpret_cast<void**>(&d_p), n * sizeof(uint32_t)), "hipMalloc");
+    chk(hipMalloc(reinterpret_cast<void**>(&d_s), n * sizeof(uint32_t)), "hipMalloc");
+    chk(hipMalloc(reinterpret_cast<void**>(&d_rgb), 3 * n * sizeof(float)), "hipMalloc");
+    if (rc == RT_OK) {
+        chk(hipMemcpy(d_p, pixel, n * sizeof(uint32_t), hipMemcpyHostToDevice), "upload");
+        chk(hipMemcpy(d_s, sample, n * sizeof(uint32_t), hipMemcpyHostToDevice), "upload");
+    }
+    if (rc == RT_OK) {
+        SceneDev S = scene->dev;
+        S.eps = descent_eps(scene, camera_abs(*cam));
+        rt_render_opts o = *opts;
+        if (o.sample_end <= o.sample_begin) { o.sample_begin = 0; o.sample_end = 1; }
+        hipLaunchKernelGGL(trace_paths_kernel, dim3(uint32_t((n + kBlock - 1) / kBlock)), dim3(kBlock), stack_bytes(scene), nullptr, S,
+                           make_cam(*cam), make_params(*cam, o), d_p, d_s, uint32_t(n), d_rgb);
+        chk(hipGetLastError(), "launch");
+        chk(hipDeviceSynchronize(), "kernel");
+        chk(hipMemcpy(rgb, d_rgb, 3 * n * sizeof(float), hipMemcpyDeviceToHost), "download");
+    }
+    (void)hipFree(d_p);
+    (void)hipFree(d_s);
+    (void)hipFree(d_rgb);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,312 @@
+"""GPU: the HIP path, called through the C ABI, against the CPU oracle and the committed golden vectors.
+
+Bars: primitive IDs bit-exact; hit parameter and normal within 1e-5 relative (they come out at
+f64 rounding level because the device runs the reference's f64 sphere test); per-path colours
+within 2e-4 except the few paths where an f32 rounding flips a discrete decision; images by PSNR.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+T_REL = 1e-5  # tolerance the parity target states for t and normals
+
+
+@pytest.fixture(scope="module")
+def scene1(rt):
+    return rt.Scene(rt.gen_scene(1))
+
+
+@pytest.fixture(scope="module")
+def oscene1(ob):
+    return ob.Scene(ob.gen_scene(1))
+
+
+def _ocam(ob, cam):
+    return ob.camera_from_bytes(bytes(cam.c))
+
+
+def _check_hits(ids, t, nrm, want_ids, want_t, want_n):
+    assert np.array_equal(ids, want_ids), "primitive IDs differ at %s" % np.nonzero(ids != want_ids)[0][:10]
+    hit = want_ids >= 0
+    assert np.all(np.abs(t[hit] - want_t[hit]) <= T_REL * np.abs(want_t[hit]))
+    assert np.all(np.abs(nrm[hit] - want_n[hit]) <= T_REL)
+    return float(np.max(np.abs(t[hit] - want_t[hit]) / np.abs(want_t[hit]))) if hit.any() else 0.0
+
+
+def test_scene_info(scene1):
+    i = scene1.info
+    assert i["n_hittables"] == 488 and i["n_spheres"] == 488 and i["n_discs"] == 0
+    assert i["n_nodes"] == 487  # one sphere per leaf: N-1 inner nodes
+    assert 9 <= i["bvh_depth"] <= 16 and i["stack_depth"] == i["bvh_depth"] + 1
+
+
+def test_primary_hits_match_golden_dump(scene1):
+    g = golden("primary_rays_seed1.npz")
+    ids, t, nrm = scene1.trace_primary(g["orig"], g["dir"])
+    worst = _check_hits(ids, t, nrm, g["id"], g["t"], g["normal"])
+    assert worst < 1e-12  # same f64 arithmetic: rounding level, far inside the 1e-5 bar
+
+
+def test_primary_hits_random_rays_match_oracle(scene1, oscene1, ob):
+    rng = np.random.default_rng(11)
+    n = 60000
+    o = np.concatenate([rng.uniform(-14, 14, (n // 2, 3)) * [1, 0.15, 1] + [0, 0.3, 0],   # among the spheres
+                        rng.normal(size=(n // 2, 3)) * [20, 5, 20] + [0, 8, 0]]).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d[: n // 4, 1] = -np.abs(d[: n // 4, 1])
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    ids, t, nrm = scene1.trace_primary(o, d)
+    want_ids, want_t, want_n, _ = oscene1.trace(o, d, ob.TRAVERSE_GATED_BRUTE)
+    _check_hits(ids, t, nrm, want_ids, want_t, want_n)
+    assert (want_ids >= 0).mean() > 0.3 and len(np.unique(want_ids)) > 300
+
+
+def test_primary_hits_exact_zero_direction_components(scene1, oscene1, ob):
+    # zero components take the 1e-4 divisor of the reference's box test (src/boundingvolume.rs:76-80)
+    o, d = [], []
+    for x in np.linspace(-10.7, 10.7, 41):
+        o += [[x, 0.2, -30.0], [x, 30.0, 0.3], [-30.0, 0.2, x]]
+        d += [[0, 0, 1.0], [0, -1.0, 0], [1.0, 0, 0]]
+    o, d = np.array(o, dtype=np.float32), np.array(d, dtype=np.float32)
+    ids, t, nrm = scene1.trace_primary(o, d)
+    want_ids, want_t, want_n, _ = oscene1.trace(o, d, ob.TRAVERSE_GATED_BRUTE)
+    _check_hits(ids, t, nrm, want_ids, want_t, want_n)
+    tree_ids, _, _, _ = oscene1.trace(o, d, ob.TRAVERSE_TREE)
+    assert np.array_equal(tree_ids, want_ids)
+
+
+def test_generate_primary_matches_oracle(scene1, ob, rt):
+    cam = rt.default_camera(96, 64)
+    o, d = scene1.generate_primary(cam, seed=5, pixel_begin=100, pixel_end=1100, sample_begin=2, sample_end=5)
+    wo, wd = ob.generate_primary(_ocam(ob, cam), 5, 100, 1100, 2, 5)
+    assert np.abs(o - wo).max() < 5e-6 and np.abs(d - wd).max() < 5e-6  # f32 camera arithmetic vs f64
+    assert np.allclose(np.linalg.norm(d.astype(np.float64), axis=1), 1, atol=3e-7)  # Ray::new normalises
+    # lens samples stay in the positive quarter disc (src/camera.rs:81-89)
+    rel = (o.astype(np.float64) - cam.field("lookfrom")) / 0.1
+    a, b = rel @ cam.field("horiz_arm"), rel @ cam.field("vert_arm")
+    assert a.min() >= -1e-5 and b.min() >= -1e-5 and (a * a + b * b).max() <= 1 + 1e-5
+
+
+def _path_parity(scene, oscene, cam, ocam, ob, n_pixels, spp, depth, seed, traverse):
+    rng = np.random.default_rng(3)
+    pixel = np.repeat(rng.choice(cam.horiz_res * cam.vert_res, n_pixels, replace=False), spp).astype(np.uint32)
+    sample = np.tile(np.arange(spp, dtype=np.uint32), n_pixels)
+    got = scene.trace_paths(cam, pixel, sample, depth=depth, seed=seed).astype(np.float64)
+    want = oscene.trace_paths(ocam, pixel, sample, depth=depth, seed=seed, traverse=traverse, sampler=ob.SAMPLER_DIRECT)
+    close = np.all(np.abs(got - want) <= 2e-4 * np.maximum(1.0, np.abs(want)), axis=1)
+    return got, want, close
+
+
+def test_paths_match_oracle_one_by_one(scene1, oscene1, ob, rt):
+    cam = rt.default_camera(160, 90)
+    got, want, close = _path_parity(scene1, oscene1, cam, _ocam(ob, cam), ob, 1500, 4, 10, 9, ob.TRAVERSE_GATED_BRUTE)
+    assert close.mean() > 0.995, "only %.4f of the paths agree" % close.mean()
+    assert abs(got.mean() - want.mean()) < 2e-3 * want.mean()
+
+
+def test_paths_depth_50(scene1, oscene1, ob, rt):
+    cam = rt.default_camera(160, 90)
+    got, want, close = _path_parity(scene1, oscene1, cam, _ocam(ob, cam), ob, 600, 4, 50, 2, ob.TRAVERSE_GATED_BRUTE)
+    assert close.mean() > 0.99
+
+
+def test_depth_rules(scene1, rt):
+    cam = rt.default_camera(32, 32)
+    px = np.arange(64, dtype=np.uint32) * 7
+    # depth 0: `for _ in 1..=0` never runs, the colour is the initial throughput (src/lib.rs:89-93, :134)
+    assert np.all(scene1.trace_paths(cam, px, np.zeros(64, np.uint32), depth=0) == 1.0)
+    s, _ = scene1.render(cam, 3, depth=0)
+    assert np.all(s == 3.0)
+    # depth 1: a hit returns the albedo (throughput after one scatter), a miss the sky
+    one = scene1.trace_paths(cam, px, np.zeros(64, np.uint32), depth=1)
+    assert one.min() >= 0 and one.max() <= 1.0
+
+
+def test_render_matches_oracle_image(scene1, oscene1, ob, rt):
+    cam = rt.default_camera(96, 64)
+    s, q = scene1.render(cam, 16, depth=10, seed=0)
+    want, want_q, st = oscene1.render(_ocam(ob, cam), spp=16, depth=10, seed=0, sampler=ob.SAMPLER_DIRECT)
+    rel = np.abs(s - want) / np.maximum(want, 1.0)
+    assert (rel.max(axis=2) < 1e-3).mean() > 0.97  # same counters, same draws: most pixels agree to f32 rounding
+    assert ob.psnr(s / 16, want / 16, peak=1.0) > 45
+    assert abs(s.sum() - want.sum()) < 1e-3 * want.sum()
+    assert (np.abs(q.astype(int) - want_q.astype(int)) <= 1).mean() > 0.97
+    # and against the reference's own sampling (rejection loops, reference tree): statistically
+    ref, _, _ = oscene1.render(_ocam(ob, cam), spp=16, depth=10, seed=0, sampler=ob.SAMPLER_REFERENCE, traverse=ob.TRAVERSE_TREE)
+    ref2, _, _ = oscene1.render(_ocam(ob, cam), spp=16, depth=10, seed=1, sampler=ob.SAMPLER_REFERENCE, traverse=ob.TRAVERSE_TREE)
+    floor = ob.psnr(ref / 16, ref2 / 16, peak=1.0)
+    assert abs(ob.psnr(s / 16, ref / 16, peak=1.0) - floor) < 1.0
+
+
+def test_converged_image_psnr_against_reference_sampling(scene1, oscene1, ob, rt):
+    # high spp, small image: device vs the oracle run with the reference's sampling and tree
+    cam = rt.default_camera(64, 40)
+    spp = 1024
+    s, _ = scene1.render(cam, spp, depth=10, seed=21)
+    a, _, _ = oscene1.render(_ocam(ob, cam), spp=spp, depth=10, seed=22, sampler=ob.SAMPLER_REFERENCE, traverse=ob.TRAVERSE_TREE)
+    b, _, _ = oscene1.render(_ocam(ob, cam), spp=spp, depth=10, seed=23, sampler=ob.SAMPLER_REFERENCE, traverse=ob.TRAVERSE_TREE)
+    floor = ob.psnr(a / spp, b / spp, peak=1.0)          # two independent reference-style renders
+    ours = ob.psnr(s / spp, a / spp, peak=1.0)
+    assert ours > floor - 0.5, (ours, floor)               # within 0.5 dB of the noise floor
+    assert abs(s.mean() / spp - a.mean() / spp) < 0.003
+
+
+def test_render_is_reproducible_and_ranges_add_up(scene1, rt):
+    cam = rt.default_camera(100, 60)  # not a multiple of the 8x8 work tile
+    a, qa = scene1.render(cam, 8, depth=10, seed=4)
+    b, qb = scene1.render(cam, 8, depth=10, seed=4)
+    assert np.array_equal(a, b) and np.array_equal(qa, qb)  # counter-based RNG, fixed summation order
+    c, _ = scene1.render(cam, 8, depth=10, seed=5)
+    assert not np.array_equal(a, c)
+    lo, _ = scene1.render(cam, 3, depth=10, seed=4, sample_begin=0)
+    hi, _ = scene1.render(cam, 5, depth=10, seed=4, sample_begin=3)
+    assert np.allclose(lo + hi, a, rtol=2e-6, atol=1e-6)  # 2 "virtual ranks" = 1 rank, up to f32 summation order
+
+
+def test_finalize_matches_color_to_ppm(scene1, ob, rt):
+    cam = rt.default_camera(64, 64)
+    s, q = scene1.render(cam, 4, depth=10, seed=1)
+    assert np.array_equal(q, ob.finalize(s.astype(np.float64), 4))  # (255*sqrt(c)) as u8 on the same sums
+
+
+def test_empty_and_single_sphere_scenes(rt, ob):
+    cam = rt.default_camera(16, 16)
+    ocam = _ocam(ob, cam)
+    empty = rt.Scene(rt.hittables([]))
+    s, _ = empty.render(cam, 2, depth=10, seed=0)
+    w, _, _ = ob.Scene(np.zeros(0, dtype=ob.HITTABLE_DTYPE)).render(ocam, spp=2, depth=10, seed=0, traverse=ob.TRAVERSE_LINEAR)
+    assert np.allclose(s, w, rtol=1e-5)  # sky only
+    ids, _, _ = empty.trace_primary([[0, 0, 0]], [[0, 0, 1]])
+    assert ids[0] == -1
+    one_h = rt.hittables([rt.sphere([0, 0, 0], 5.0, rt.diffuse([0.4, 0.2, 0.1]))])  # src/scenegen.rs:111-127
+    one = rt.Scene(one_h)
+    ids, t, n = one.trace_primary([[10, 0, 0], [10, 0, 0], [0, 0, 0]], [[1, 0, 0], [-1, 0, 0], [0, 1, 0]])
+    assert list(ids) == [-1, 0, 0] and t[1] == 5.0 and t[2] == 5.0 and list(n[1]) == [1, 0, 0]
+
+
+def test_reference_inline_cases_on_device(rt):
+    # src/geometry.rs:162-174 and src/boundingvolume.rs:451-502 through the device path
+    s = rt.Scene(rt.hittables([rt.sphere([0, 0, 0], 2.0, rt.diffuse([1, 1, 1]))]))
+    ids, t, n = s.trace_primary([[0, 0, -3]], [[0, 0, 1]])
+    assert ids[0] == 0 and t[0] == 1.0 and list(n[0]) == [0, 0, -1]
+    s = rt.Scene(rt.hittables([rt.sphere([0, 0, 0], 1.0, rt.diffuse([1, 1, 1]))]))
+    assert s.trace_primary([[2, 0, 0]], [[1, 0, 0]])[0][0] == -1
+    three = rt.Scene(rt.hittables([rt.sphere([0, 0, 0], 5.0, rt.diffuse([1, 1, 1])), rt.sphere([0, 0, 2], 1.0, rt.diffuse([1, 1, 1])),
+                                   rt.sphere([0, 2, 0], 1.0, rt.diffuse([1, 1, 1]))]))
+    ids, t, _ = three.trace_primary([[-1.5, -0.5, -0.5]], [[1, 0, 0]])
+    assert ids[0] == 0 and np.isfinite(t[0]) and t[0] > 6
+
+
+def test_equal_parameters_resolve_to_lowest_id(rt):
+    dup = rt.hittables([rt.sphere([0, 0, 5], 1.0, rt.diffuse([1, 0, 0])), rt.sphere([3, 0, 5], 1.0, rt.diffuse([0, 1, 0])),
+                        rt.sphere([0, 0, 5], 1.0, rt.diffuse([0, 0, 1]))])
+    s = rt.Scene(dup)
+    ids, _, _ = s.trace_primary([[0, 0, 0], [3, 0, 0]], [[0, 0, 1], [0, 0, 1]])
+    assert list(ids) == [0, 1]
+
+
+def test_bundled_scene_json_disc_emitter_texture(rt, ob, earth_rgb8):
+    import os
+
+    from conftest import GOLDEN
+
+    cfg = rt.Config.from_json(os.path.join(GOLDEN, "scene.json"), texture_loader=lambda p: earth_rgb8)
+    scene = rt.Scene(cfg.hittables, cfg.textures)
+    assert scene.info["n_discs"] == 1 and scene.info["n_spheres"] == 4
+    oscene = ob.Scene(cfg.hittables, cfg.textures)
+    cam = rt.Camera.build([0, 0, 1], [0, 1.5, -5], 1.0, 0.1, 128, 128)
+    ocam = _ocam(ob, cam)
+    # nearest hits incl. the disc's negative parameters (src/geometry.rs:133-139 has no h > 0 test)
+    o, d = scene.generate_primary(cam, seed=0, pixel_begin=0, pixel_end=128 * 128)
+    ids, t, nrm = scene.trace_primary(o, d)
+    want_ids, want_t, want_n, _ = oscene.trace(o, d, ob.TRAVERSE_LINEAR)
+    _check_hits(ids, t, nrm, want_ids, want_t, want_n)
+    assert (want_ids == 2).any() and (want_t[want_ids == 2] < 0).any()
+    got, want, close = _path_parity(scene, oscene, cam, ocam, ob, 1500, 4, 10, 6, ob.TRAVERSE_LINEAR)
+    assert close.mean() > 0.99
+    s, q = scene.render(cam, 8, depth=10, seed=0)
+    w, wq, _ = oscene.render(ocam, spp=8, depth=10, seed=0, traverse=ob.TRAVERSE_LINEAR)
+    assert ob.psnr(s / 8, w / 8, peak=1.0) > 40
+
+
+def test_accel_render_refuses_discs_like_the_reference_tree(rt, earth_rgb8, tmp_path):
+    import os
+
+    from conftest import GOLDEN
+
+    cfg = rt.Config.from_json(os.path.join(GOLDEN, "scene.json"), texture_loader=lambda p: earth_rgb8)
+    scene = rt.Scene(cfg.hittables, cfg.textures)
+    cam = rt.Camera.build([0, 0, 1], [0, 1.5, -5], 1.0, 0.1, 16, 16)
+    with open(tmp_path / "a.ppm", "w") as f:
+        with pytest.raises(rt.RtError):
+            rt.accel_render_into_file(f, cam, scene, 1)  # unimplemented!() at src/boundingvolume.rs:254-256
+    with open(tmp_path / "image.ppm", "w") as f:
+        f.write(rt.ppm_header(cam))
+        rt.render_into_file(f, cam, scene, 2)
+    lines = open(tmp_path / "image.ppm").read().split("\n")
+    assert lines[:3] == ["P3", "16 16", "255"] and len(lines) == 3 + 256 + 1
+    assert all(0 <= int(v) <= 255 for v in lines[3].split())
+
+
+def test_texture_albedo_on_device(rt, ob, earth_rgb8):
+    # a lone textured sphere lit by the sky: depth-1 colours are the texel colours
+    h = rt.hittables([rt.sphere([0, 0.2, 3.0], 0.75, rt.texture_map(0, [0, 1, -0.6], [1, 0, 0.5]))])
+    scene, oscene = rt.Scene(h, [earth_rgb8]), ob.Scene(h, [earth_rgb8])
+    cam = rt.Camera.build([0, 0.2, 3.0], [0, 1.5, -5], 0.2, 0.0, 96, 96)
+    px = np.arange(96 * 96, dtype=np.uint32)
+    got = scene.trace_paths(cam, px, np.zeros_like(px), depth=1, seed=0).astype(np.float64)
+    want = oscene.trace_paths(_ocam(ob, cam), px, np.zeros_like(px), depth=1, seed=0, traverse=ob.TRAVERSE_LINEAR)
+    same = np.all(np.abs(got - want) < 1e-6, axis=1)
+    assert same.mean() > 0.995  # f32 acos/atan2 can cross a texel boundary
+
+
+def test_nested_dielectric_shells_deep_bounces(rt, ob, earth_rgb8):
+    h = rt.gen_scene_shells(6)
+    scene, oscene = rt.Scene(h, [earth_rgb8]), ob.Scene(h, [earth_rgb8])
+    cam = rt.Camera.build([0, 0, 1], [0, 1.5, -5], 1.0, 0.1, 96, 96)
+    got, want, close = _path_parity(scene, oscene, cam, _ocam(ob, cam), ob, 1200, 4, 50, 1, ob.TRAVERSE_GATED_BRUTE)
+    assert close.mean() > 0.98
+    assert abs(got.mean() - want.mean()) < 5e-3 * want.mean()
+
+
+def test_grid_scene_primary_hits(rt, ob):
+    h = rt.gen_scene_grid(2, 48)  # 2305 spheres on the ground sphere
+    scene, oscene = rt.Scene(h), ob.Scene(h)
+    cam = rt.Camera.build([0, 0, 0], [20, 6, 8], 1.0, 0.05, 128, 80)
+    o, d = scene.generate_primary(cam, seed=1, pixel_begin=0, pixel_end=128 * 80)
+    ids, t, nrm = scene.trace_primary(o, d)
+    want_ids, want_t, want_n, _ = oscene.trace(o, d, ob.TRAVERSE_GATED_BRUTE)
+    _check_hits(ids, t, nrm, want_ids, want_t, want_n)
+    assert len(np.unique(want_ids)) > 500
+
+
+def test_full_size_properties_1080p(scene1, rt):
+    # the bench workload's size: properties that need no oracle
+    cam = rt.default_camera(1920, 1080)
+    s, q = scene1.render(cam, 2, depth=50, seed=0)
+    assert s.shape == (1080, 1920, 3) and np.isfinite(s).all() and s.min() >= 0 and s.max() <= 2.0 + 1e-5
+    assert 0.4 < s.mean() / 2 < 0.9
+    a, _ = scene1.render(cam, 1, depth=50, seed=0, sample_begin=0)
+    b, _ = scene1.render(cam, 1, depth=50, seed=0, sample_begin=1)
+    assert np.allclose(a + b, s, rtol=2e-6, atol=1e-6)
+    s2, q2 = scene1.render(cam, 2, depth=50, seed=0)
+    assert np.array_equal(q, q2)
+
+
+def test_argument_errors(scene1, rt):
+    cam = rt.default_camera(16, 16)
+    with pytest.raises(rt.RtError) as e:
+        scene1.render(cam, 0)
+    assert e.value.status == 1 and "empty sample range" in str(e.value)
+    with pytest.raises(rt.RtError):
+        scene1.trace_paths(cam, np.array([16 * 16], dtype=np.uint32), np.array([0], dtype=np.uint32))
+    with pytest.raises(rt.RtError):
+        scene1.trace_primary([[np.nan, 0, 0]], [[0, 0, 1]])
+    bad = rt.gen_scene(1)[:3].copy()
+    bad[1]["material"] = 9
+    with pytest.raises(rt.RtError) as e:
+        rt.Scene(bad)
+    assert e.value.status == 2
