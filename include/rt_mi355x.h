@@ -177,6 +177,14 @@ int rt_generate_primary(rt_scene* scene, const rt_camera* cam, uint64_t seed, ui
 int rt_trace_paths(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, const uint32_t* pixel,
                    const uint32_t* sample, size_t n, float* rgb);
 
+/* The same paths, segment by segment: what the loop of src/lib.rs:93-131 sees on each turn.
+ * seg_id[k*max_segments + i] / seg_t[...] = primitive ID (-1 = the miss that ends the path) and
+ * parameter of segment i of path k, for i < min(n_seg[k], max_segments); n_seg[k] = segments traced.
+ * rgb is optional here.  Host buffers. */
+int rt_trace_path_segments(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, const uint32_t* pixel,
+                           const uint32_t* sample, size_t n, float* rgb, uint32_t max_segments, int32_t* seg_id,
+                           double* seg_t, uint32_t* n_seg);
+
 /* src/main.rs:35-42 + src/lib.rs:151: "P3\nW H\n255\n" then one "r g b\n" line
  * per pixel.  Unlike the reference the file is truncated first. */
 int rt_write_ppm(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height);

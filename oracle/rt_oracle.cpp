@@ -147,14 +147,31 @@ double orc_render(const orc_scene* s, const Camera* cam, int traverse, int sampl
 }
 
 // Radiance of single paths (pixel, sample) — lets a test compare path by path.
+// segments (optional) receives the number of segments each path traced.
 void orc_trace_paths(const orc_scene* s, const Camera* cam, int traverse, int sampler, const uint32_t* pixel,
-                     const uint32_t* sample, size_t n, uint32_t depth, uint64_t seed, double* rgb) {
+                     const uint32_t* sample, size_t n, uint32_t depth, uint64_t seed, double* rgb, uint32_t* segments) {
     std::vector<Candidate> scratch;
     for (size_t k = 0; k < n; ++k) {
         Sampler smp(sampler, seed, pixel[k], sample[k]);
         Ray r = camera_ray(*cam, pixel[k] % cam->horiz_res, pixel[k] / cam->horiz_res, smp);
-        Color c = trace(s->sc, traverse, r, depth, smp, scratch, nullptr);
+        TraceCounters ctr;
+        Color c = trace(s->sc, traverse, r, depth, smp, scratch, &ctr);
         rgb[3 * k] = c.r; rgb[3 * k + 1] = c.g; rgb[3 * k + 2] = c.b;
+        if (segments) segments[k] = uint32_t(ctr.segments);
+    }
+}
+
+// Segment-by-segment dump of single paths (primitive ID, -1 = closing miss; parameter).
+void orc_path_segments(const orc_scene* s, const Camera* cam, int traverse, int sampler, const uint32_t* pixel,
+                       const uint32_t* sample, size_t n, uint32_t depth, uint64_t seed, uint32_t max_segments,
+                       int32_t* seg_id, double* seg_t, uint32_t* n_seg) {
+    std::vector<Candidate> scratch;
+    for (size_t k = 0; k < n; ++k) {
+        Sampler smp(sampler, seed, pixel[k], sample[k]);
+        Ray r = camera_ray(*cam, pixel[k] % cam->horiz_res, pixel[k] / cam->horiz_res, smp);
+        SegmentLog log{seg_id + k * max_segments, seg_t + k * max_segments, max_segments, 0};
+        trace(s->sc, traverse, r, depth, smp, scratch, nullptr, &log);
+        n_seg[k] = log.n;
     }
 }
 

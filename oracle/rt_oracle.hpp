@@ -566,14 +566,18 @@ inline void candidates(const Scene& sc, int traverse, const Ray& ray, std::vecto
 }
 
 // lib.rs:40-86 and :88-135 (identical bodies apart from the candidate source).
+struct SegmentLog { int32_t* id; double* t; uint32_t cap; uint32_t n; };
+
 inline Color trace(const Scene& sc, int traverse, Ray ray, uint32_t depth, Sampler& s, std::vector<Candidate>& scratch,
-                   TraceCounters* ctr) {
+                   TraceCounters* ctr, SegmentLog* log = nullptr) {
     Color color{1.0, 1.0, 1.0};
     for (uint32_t bounce = 1; bounce <= depth; ++bounce) {
         candidates(sc, traverse, ray, scratch, ctr);
         if (ctr) ctr->segments++;
-        int idx; double t;
-        if (nearest(scratch, sc.tie_lowest_index || traverse != TRAVERSE_TREE, &idx, &t)) {
+        int idx = -1; double t = 0.0;
+        const bool found = nearest(scratch, sc.tie_lowest_index || traverse != TRAVERSE_TREE, &idx, &t);
+        if (log) { if (log->n < log->cap) { log->id[log->n] = found ? idx : -1; log->t[log->n] = found ? t : 0.0; } log->n++; }
+        if (found) {
             const Hittable& h = sc.hittables[idx];
             Vec3 loc = ray.position_at(t);
             if (h.material == MAT_EMITTER) {  // lib.rs:101-104: drops the throughput

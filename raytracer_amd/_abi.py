@@ -107,6 +107,7 @@ PROTOTYPES = {
     "rt_trace_primary": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     "rt_generate_primary": (_i, [_vp, C.POINTER(rt_camera), _u64, _u32, _u32, _u32, _u32, _vp, _vp]),
     "rt_trace_paths": (_i, [_vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts), _vp, _vp, _sz, _vp]),
+    "rt_trace_path_segments": (_i, [_vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts), _vp, _vp, _sz, _vp, _u32, _vp, _vp, _vp]),
     "rt_write_ppm": (_i, [C.c_char_p, _vp, _u32, _u32]),
 }
 

@@ -212,6 +212,23 @@ class Scene:
         return rgb
 
 
+def _path_segments(self, cam, pixel, sample, depth=REFERENCE_DEPTH, seed=0, max_segments=16):
+    """Per path: (ids (n,max_segments) int32, -1 = the closing miss / unused; t float64; n_seg uint32)."""
+    p = np.ascontiguousarray(pixel, dtype=np.uint32)
+    s = np.ascontiguousarray(sample, dtype=np.uint32)
+    n = p.shape[0]
+    ids = np.full((n, max_segments), -1, dtype=np.int32)
+    t = np.zeros((n, max_segments), dtype=np.float64)
+    n_seg = np.zeros(n, dtype=np.uint32)
+    o = self.opts(0, 1, depth, seed)
+    check(lib.rt_trace_path_segments(self.handle, C.byref(cam.c), C.byref(o), ptr(p), ptr(s), n, None, int(max_segments),
+                                     ptr(ids), ptr(t), ptr(n_seg)))
+    return ids, t, n_seg
+
+
+Scene.path_segments = _path_segments
+
+
 def write_ppm(path, rgb8):
     a = np.ascontiguousarray(rgb8, dtype=np.uint8)
     check(lib.rt_write_ppm(os.fsencode(path), ptr(a), a.shape[1], a.shape[0]))

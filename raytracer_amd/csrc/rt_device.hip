@@ -175,13 +175,13 @@ __device__ __forceinline__ void consider(Best& b, double t, int32_t k, int32_t i
 // (entry `level` lives at stk[level * kBlock]).  GATE adds the reference's
 // own-box line test in front of every sphere test (bit-exact candidate set).
 template <bool GATE>
-__device__ __forceinline__ Best closest_hit(const SceneDev& S, double ox, double oy, double oz, float dxf, float dyf,
-                                            float dzf, int32_t* stk) {
+__device__ __forceinline__ Best closest_hit(const SceneDev& S, double ox, double oy, double oz, double dx, double dy,
+                                            double dz, int32_t* stk) {
     Best best;
     best.t = 0.0;
     best.k = -1;
     best.id = 0x7fffffff;
-    const double dx = double(dxf), dy = double(dyf), dz = double(dzf);
+    const float dxf = float(dx), dyf = float(dy), dzf = float(dz);
 
     // discs first, one by one, with LINE semantics (negative parameters count)
     for (int32_t i = 0; i < S.n_discs; ++i) {
@@ -266,14 +266,26 @@ __device__ __forceinline__ Best closest_hit(const SceneDev& S, double ox, double
 // ---------------------------------------------------------------- shading
 struct Path {
     double ox, oy, oz;
-    float dx, dy, dz;
-    float tr, tg, tb;  // throughput ("color" in src/lib.rs:89)
+    double dx, dy, dz;  // unit to f64 rounding, see unit_f64
+    float tr, tg, tb;   // throughput ("color" in src/lib.rs:89)
     uint32_t pixel, sample, bounce;
 };
 
 __device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
     float inv = rsqrtf(x * x + y * y + z * z);
     x *= inv; y *= inv; z *= inv;
+}
+
+// Sphere::intersect (src/geometry.rs:104-121) drops the quadratic's leading
+// coefficient, so the hit point lies on the sphere only as well as |dir| = 1
+// holds; its 1e-6 self-intersection guard assumes f64 accuracy there.  An
+// f32-normalised direction (|d|^2 = 1 + e, |e| ~ 1e-7) is rescaled in f64 by the
+// series of 1/sqrt(1 + e), which leaves |d| = 1 to f64 rounding.
+__device__ __forceinline__ void unit_f64(float x, float y, float z, double* X, double* Y, double* Z) {
+    const double a = double(x), b = double(y), c = double(z);
+    const double e = (a * a + b * b + c * c) - 1.0;
+    const double k = 1.0 - 0.5 * e + 0.375 * (e * e);
+    *X = a * k; *Y = b * k; *Z = c * k;
 }
 
 // src/camera.rs:49-78 + src/ray.rs:9-11 with the two rejection loops replaced
@@ -301,7 +313,7 @@ __device__ __forceinline__ void start_path(const CamDev& C, const RenderParams& 
     float o[3], d[3];
     camera_ray(C, P, pixel, sample, o, d);
     p.ox = double(o[0]); p.oy = double(o[1]); p.oz = double(o[2]);
-    p.dx = d[0]; p.dy = d[1]; p.dz = d[2];
+    unit_f64(d[0], d[1], d[2], &p.dx, &p.dy, &p.dz);
     p.tr = p.tg = p.tb = 1.0f;
     p.pixel = pixel; p.sample = sample; p.bounce = 1;
 }
@@ -328,10 +340,12 @@ __device__ __forceinline__ void texture_albedo(const SceneDev& S, int32_t texmat
 // One segment of accel_raytrace / raytrace (src/lib.rs:93-131).  Returns true
 // when the path goes on; otherwise (Lr,Lg,Lb) is the value the reference returns.
 __device__ __forceinline__ bool advance(const SceneDev& S, const RenderParams& P, Path& p, int32_t* stk, float& Lr,
-                                        float& Lg, float& Lb) {
+                                        float& Lg, float& Lb, int32_t* hit_id = nullptr, double* hit_t = nullptr) {
     const Best hit = closest_hit<false>(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, stk);
+    if (hit_id) { *hit_id = hit.k < 0 ? -1 : hit.id; *hit_t = hit.t; }
+    const float dxf = float(p.dx), dyf = float(p.dy), dzf = float(p.dz);
     if (hit.k < 0) {  // src/lib.rs:117-130
-        const float t = 0.5f * (p.dy + 1.0f);
+        const float t = 0.5f * (dyf + 1.0f);
         Lr = p.tr * ((1.0f - t) + t * 0.5f);
         Lg = p.tg * ((1.0f - t) + t * 0.7f);
         Lb = p.tb * ((1.0f - t) + t * 1.0f);
@@ -341,9 +355,9 @@ __device__ __forceinline__ bool advance(const SceneDev& S, const RenderParams& P
     double hx, hy, hz;  // scatter_loc = orig + t*dir (src/ray.rs:12-14)
     {
 #pragma clang fp contract(off)
-        hx = p.ox + hit.t * double(p.dx);
-        hy = p.oy + hit.t * double(p.dy);
-        hz = p.oz + hit.t * double(p.dz);
+        hx = p.ox + hit.t * p.dx;
+        hy = p.oy + hit.t * p.dy;
+        hz = p.oz + hit.t * p.dz;
     }
     float nx, ny, nz;     // normal_at
     float lx, ly, lz;     // obj_relative_loc (src/lib.rs:106-113)
@@ -362,7 +376,7 @@ __device__ __forceinline__ bool advance(const SceneDev& S, const RenderParams& P
     const int32_t kind_word = S.kind[k];
     const int32_t kind = kind_word & 0xff;
     const float4 m = S.mat[k];
-    const float ddn = p.dx * nx + p.dy * ny + p.dz * nz;
+    const float ddn = dxf * nx + dyf * ny + dzf * nz;
     if (kind == RT_MAT_EMITTER) {  // src/lib.rs:101-104: the throughput is dropped
         const float c = fabsf(ddn);
         Lr = m.x * c; Lg = m.y * c; Lb = m.z * c;
@@ -377,7 +391,7 @@ __device__ __forceinline__ bool advance(const SceneDev& S, const RenderParams& P
         sx = nx + vx; sy = ny + vy; sz = nz + vz;
         if (kind == RT_MAT_TEXTUREMAP) texture_albedo(S, kind_word >> 8, lx, ly, lz, &ar, &ag, &ab);
     } else if (kind == RT_MAT_METAL) {  // src/materials.rs:86-95, fuzzify :141-148
-        const float rx = p.dx - 2.0f * ddn * nx, ry = p.dy - 2.0f * ddn * ny, rz = p.dz - 2.0f * ddn * nz;
+        const float rx = dxf - 2.0f * ddn * nx, ry = dyf - 2.0f * ddn * ny, rz = dzf - 2.0f * ddn * nz;
         bool accepted = false;
         sx = rx; sy = ry; sz = rz;
         for (uint32_t attempt = 0; attempt < uint32_t(kFuzzMaxAttempts); ++attempt) {
@@ -393,7 +407,7 @@ __device__ __forceinline__ bool advance(const SceneDev& S, const RenderParams& P
         }
     } else {  // RT_MAT_DIELECTRIC, src/materials.rs:96-121
         const float inc_cos = ddn;
-        const float px = p.dx - inc_cos * nx, py = p.dy - inc_cos * ny, pz = p.dz - inc_cos * nz;
+        const float px = dxf - inc_cos * nx, py = dyf - inc_cos * ny, pz = dzf - inc_cos * nz;
         const bool entering = __float_as_uint(inc_cos) >> 31;  // signum < 0 (also for -0.0)
         const float ratio = entering ? 1.0f / m.w : m.w;
         const float qx = ratio * px, qy = ratio * py, qz = ratio * pz;
@@ -418,7 +432,7 @@ __device__ __forceinline__ bool advance(const SceneDev& S, const RenderParams& P
     normalize3(sx, sy, sz);  // Ray::new
     p.tr *= ar; p.tg *= ag; p.tb *= ab;
     p.ox = hx; p.oy = hy; p.oz = hz;
-    p.dx = sx; p.dy = sy; p.dz = sz;
+    unit_f64(sx, sy, sz, &p.dx, &p.dy, &p.dz);
     if (p.bounce >= P.depth) {  // src/lib.rs:134: depth exhausted returns the throughput
         Lr = p.tr; Lg = p.tg; Lb = p.tb;
         return false;
@@ -440,7 +454,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(SceneDev S, CamDev C, Re
 
     Path p;
     p.ox = p.oy = p.oz = 0.0;
-    p.dx = p.dy = p.dz = 0.0f;
+    p.dx = p.dy = p.dz = 0.0;
     p.tr = p.tg = p.tb = 0.0f;
     p.pixel = 0; p.sample = 0; p.bounce = 0;
     bool have_pixel = false, alive = false, done = false;
@@ -512,6 +526,33 @@ __global__ __launch_bounds__(kBlock) void trace_paths_kernel(SceneDev S, CamDev 
     rgb[3 * size_t(g)] = Lr; rgb[3 * size_t(g) + 1] = Lg; rgb[3 * size_t(g) + 2] = Lb;
 }
 
+// One thread per listed path: the primitive ID and parameter of every segment (id -1 = the miss that ends it).
+__global__ __launch_bounds__(kBlock) void path_segments_kernel(SceneDev S, CamDev C, RenderParams P,
+                                                               const uint32_t* __restrict__ pixel,
+                                                               const uint32_t* __restrict__ sample, uint32_t n,
+                                                               uint32_t max_segments, int32_t* __restrict__ seg_id,
+                                                               double* __restrict__ seg_t, uint32_t* __restrict__ n_seg) {
+    extern __shared__ int32_t stack_lds[];
+    int32_t* stk = stack_lds + threadIdx.x;
+    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
+    if (g >= n) return;
+    uint32_t count = 0;
+    if (P.depth > 0) {
+        Path p;
+        start_path(C, P, pixel[g], sample[g], p);
+        float Lr, Lg, Lb;
+        bool go = true;
+        while (go) {
+            int32_t id;
+            double t;
+            go = advance(S, P, p, stk, Lr, Lg, Lb, &id, &t);
+            if (count < max_segments) { seg_id[size_t(g) * max_segments + count] = id; seg_t[size_t(g) * max_segments + count] = t; }
+            ++count;
+        }
+    }
+    n_seg[g] = count;
+}
+
 __global__ __launch_bounds__(kBlock) void generate_primary_kernel(CamDev C, RenderParams P, uint32_t pixel_begin,
                                                                   uint32_t ns, uint32_t n, float* __restrict__ orig,
                                                                   float* __restrict__ dir) {
@@ -533,7 +574,7 @@ __global__ __launch_bounds__(kBlock) void trace_primary_kernel(SceneDev S, const
     if (g >= n) return;
     const double ox = double(orig[3 * size_t(g)]), oy = double(orig[3 * size_t(g) + 1]), oz = double(orig[3 * size_t(g) + 2]);
     const float dx = dir[3 * size_t(g)], dy = dir[3 * size_t(g) + 1], dz = dir[3 * size_t(g) + 2];
-    const Best hit = closest_hit<true>(S, ox, oy, oz, dx, dy, dz, stk);
+    const Best hit = closest_hit<true>(S, ox, oy, oz, double(dx), double(dy), double(dz), stk);
     if (hit.k < 0) { id[g] = -1; return; }
     id[g] = hit.id;
     t[g] = hit.t;
@@ -968,7 +1009,16 @@ int rt_generate_primary(rt_scene* scene, const rt_camera* cam, uint64_t seed, ui
 
 int rt_trace_paths(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, const uint32_t* pixel,
                    const uint32_t* sample, size_t n, float* rgb) {
-    if (!scene || !cam || !opts || !pixel || !sample || !rgb) return fail(RT_ERR_INVALID_ARGUMENT, "rt_trace_paths: null argument");
+    return rt_trace_path_segments(scene, cam, opts, pixel, sample, n, rgb, 0, nullptr, nullptr, nullptr);
+}
+
+int rt_trace_path_segments(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, const uint32_t* pixel,
+                           const uint32_t* sample, size_t n, float* rgb, uint32_t max_segments, int32_t* seg_id,
+                           double* seg_t, uint32_t* n_seg) {
+    if (!scene || !cam || !opts || !pixel || !sample) return fail(RT_ERR_INVALID_ARGUMENT, "rt_trace_paths: null argument");
+    if (!rgb && !n_seg) return fail(RT_ERR_INVALID_ARGUMENT, "rt_trace_paths: no output requested");
+    if (n_seg && max_segments && (!seg_id || !seg_t)) return fail(RT_ERR_INVALID_ARGUMENT, "rt_trace_path_segments: null segment buffers");
+    if (uint64_t(n) * max_segments > (uint64_t(1) << 31)) return fail(RT_ERR_LIMIT, "rt_trace_path_segments: more than 2^31 segment records");
     if (cam->horiz_res == 0 || cam->vert_res == 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_trace_paths: zero resolution");
     if (n == 0) return RT_OK;
     if (n > 0x7fffffffull - kBlock) return fail(RT_ERR_LIMIT, "rt_trace_paths: more than 2^31 paths in one call");
@@ -976,13 +1026,22 @@ int rt_trace_paths(rt_scene* scene, const rt_camera* cam, const rt_render_opts* 
     for (size_t k = 0; k < n; ++k)
         if (pixel[k] >= n_pixels) return fail(RT_ERR_INVALID_ARGUMENT, "rt_trace_paths: pixel %u of %llu", pixel[k], (unsigned long long)n_pixels);
     RT_HIP(hipSetDevice(scene->device));
-    uint32_t *d_p = nullptr, *d_s = nullptr;
+    uint32_t *d_p = nullptr, *d_s = nullptr, *d_nseg = nullptr;
     float* d_rgb = nullptr;
+    int32_t* d_sid = nullptr;
+    double* d_st = nullptr;
+    const size_t n_rec = std::max<size_t>(size_t(n) * max_segments, 1);
     int rc = RT_OK;
     auto chk = [&](hipError_t e, const char* what) { if (e != hipSuccess && rc == RT_OK) rc = fail(RT_ERR_DEVICE, "rt_trace_paths: %s failed: %s", what, hipGetErrorString(e)); };
     chk(hipMalloc(reinterpret_cast<void**>(&d_p), n * sizeof(uint32_t)), "hipMalloc");
     chk(hipMalloc(reinterpret_cast<void**>(&d_s), n * sizeof(uint32_t)), "hipMalloc");
     chk(hipMalloc(reinterpret_cast<void**>(&d_rgb), 3 * n * sizeof(float)), "hipMalloc");
+    if (n_seg) {
+        chk(hipMalloc(reinterpret_cast<void**>(&d_nseg), n * sizeof(uint32_t)), "hipMalloc");
+        chk(hipMalloc(reinterpret_cast<void**>(&d_sid), n_rec * sizeof(int32_t)), "hipMalloc");
+        chk(hipMalloc(reinterpret_cast<void**>(&d_st), n_rec * sizeof(double)), "hipMalloc");
+        if (rc == RT_OK) { chk(hipMemset(d_sid, 0xff, n_rec * sizeof(int32_t)), "memset"); chk(hipMemset(d_st, 0, n_rec * sizeof(double)), "memset"); }
+    }
     if (rc == RT_OK) {
         chk(hipMemcpy(d_p, pixel, n * sizeof(uint32_t), hipMemcpyHostToDevice), "upload");
         chk(hipMemcpy(d_s, sample, n * sizeof(uint32_t), hipMemcpyHostToDevice), "upload");
@@ -992,15 +1051,33 @@ int rt_trace_paths(rt_scene* scene, const rt_camera* cam, const rt_render_opts* 
         S.eps = descent_eps(scene, camera_abs(*cam));
         rt_render_opts o = *opts;
         if (o.sample_end <= o.sample_begin) { o.sample_begin = 0; o.sample_end = 1; }
-        hipLaunchKernelGGL(trace_paths_kernel, dim3(uint32_t((n + kBlock - 1) / kBlock)), dim3(kBlock), stack_bytes(scene), nullptr, S,
-                           make_cam(*cam), make_params(*cam, o), d_p, d_s, uint32_t(n), d_rgb);
-        chk(hipGetLastError(), "launch");
+        const dim3 grid(uint32_t((n + kBlock - 1) / kBlock));
+        if (rgb) {
+            hipLaunchKernelGGL(trace_paths_kernel, grid, dim3(kBlock), stack_bytes(scene), nullptr, S, make_cam(*cam),
+                               make_params(*cam, o), d_p, d_s, uint32_t(n), d_rgb);
+            chk(hipGetLastError(), "launch");
+        }
+        if (n_seg) {
+            hipLaunchKernelGGL(path_segments_kernel, grid, dim3(kBlock), stack_bytes(scene), nullptr, S, make_cam(*cam),
+                               make_params(*cam, o), d_p, d_s, uint32_t(n), max_segments, d_sid, d_st, d_nseg);
+            chk(hipGetLastError(), "launch");
+        }
         chk(hipDeviceSynchronize(), "kernel");
-        chk(hipMemcpy(rgb, d_rgb, 3 * n * sizeof(float), hipMemcpyDeviceToHost), "download");
+        if (rgb) chk(hipMemcpy(rgb, d_rgb, 3 * n * sizeof(float), hipMemcpyDeviceToHost), "download");
+        if (n_seg) {
+            chk(hipMemcpy(n_seg, d_nseg, n * sizeof(uint32_t), hipMemcpyDeviceToHost), "download");
+            if (max_segments) {
+                chk(hipMemcpy(seg_id, d_sid, size_t(n) * max_segments * sizeof(int32_t), hipMemcpyDeviceToHost), "download");
+                chk(hipMemcpy(seg_t, d_st, size_t(n) * max_segments * sizeof(double), hipMemcpyDeviceToHost), "download");
+            }
+        }
     }
     (void)hipFree(d_p);
     (void)hipFree(d_s);
     (void)hipFree(d_rgb);
+    (void)hipFree(d_nseg);
+    (void)hipFree(d_sid);
+    (void)hipFree(d_st);
     return rc;
 }
 

@@ -69,7 +69,8 @@ def lib():
         L.orc_generate_primary.argtypes = [C.POINTER(Camera), u64, i, u32, u32, u32, u32, vp, vp]
         L.orc_render.restype = d
         L.orc_render.argtypes = [vp, C.POINTER(Camera), i, i, u32, u32, u32, u64, i, u32, u32, vp, vp, vp]
-        L.orc_trace_paths.argtypes = [vp, C.POINTER(Camera), i, i, vp, vp, sz, u32, u64, vp]
+        L.orc_trace_paths.argtypes = [vp, C.POINTER(Camera), i, i, vp, vp, sz, u32, u64, vp, vp]
+        L.orc_path_segments.argtypes = [vp, C.POINTER(Camera), i, i, vp, vp, sz, u32, u64, u32, vp, vp, vp]
         L.orc_finalize.argtypes = [vp, sz, d, vp]
         L.orc_philox4x32_10.argtypes = [vp, vp, vp]
         L.orc_sphere_intersect.argtypes = [vp, d, vp, vp, i, vp]
@@ -165,14 +166,31 @@ class Scene:
                                 r0, r1, s.ctypes.data, q.ctypes.data, ctr.ctypes.data)
         return s, q, {"seconds": secs, "box_tests": int(ctr[0]), "shape_tests": int(ctr[1]), "segments": int(ctr[2]), "paths": int(ctr[3]), "threads": th}
 
-    def trace_paths(self, cam, pixel, sample, depth=10, seed=0, traverse=TRAVERSE_GATED_BRUTE, sampler=SAMPLER_DIRECT):
+    def trace_paths(self, cam, pixel, sample, depth=10, seed=0, traverse=TRAVERSE_GATED_BRUTE, sampler=SAMPLER_DIRECT,
+                    with_segments=False):
         p = np.ascontiguousarray(pixel, dtype=np.uint32)
         s = np.ascontiguousarray(sample, dtype=np.uint32)
         rgb = np.zeros((p.shape[0], 3))
+        seg = np.zeros(p.shape[0], dtype=np.uint32)
         if traverse == TRAVERSE_TREE and self.tree_nodes is None:
             self.build_tree()
-        lib().orc_trace_paths(self.handle, C.byref(cam), traverse, sampler, p.ctypes.data, s.ctypes.data, p.shape[0], depth, seed, rgb.ctypes.data)
-        return rgb
+        lib().orc_trace_paths(self.handle, C.byref(cam), traverse, sampler, p.ctypes.data, s.ctypes.data, p.shape[0], depth, seed,
+                              rgb.ctypes.data, seg.ctypes.data)
+        return (rgb, seg) if with_segments else rgb
+
+    def path_segments(self, cam, pixel, sample, depth=10, seed=0, traverse=TRAVERSE_GATED_BRUTE, sampler=SAMPLER_DIRECT,
+                      max_segments=16):
+        p = np.ascontiguousarray(pixel, dtype=np.uint32)
+        s = np.ascontiguousarray(sample, dtype=np.uint32)
+        n = p.shape[0]
+        ids = np.full((n, max_segments), -1, dtype=np.int32)
+        t = np.zeros((n, max_segments))
+        n_seg = np.zeros(n, dtype=np.uint32)
+        if traverse == TRAVERSE_TREE and self.tree_nodes is None:
+            self.build_tree()
+        lib().orc_path_segments(self.handle, C.byref(cam), traverse, sampler, p.ctypes.data, s.ctypes.data, n, depth, seed,
+                                max_segments, ids.ctypes.data, t.ctypes.data, n_seg.ctypes.data)
+        return ids, t, n_seg
 
     def albedo(self, index, loc):
         l = f64(loc)
