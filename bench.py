@@ -29,38 +29,23 @@ def cpu_baseline(hittables, budget_s):
     scene = ob.Scene(hittables)
     scene.build_tree()
     cam = ob.camera_build([0, 0, 0], [13, 1.5, 3], 1.0, 0.1, WIDTH, HEIGHT)
-    rows, spp = (0, HEIGHT), 1
-    # calibrate on 8 rows spread over the image, then size the sample for the budget
-    t0 = time.time()
-    cal_paths = cal_segs = 0
-    for r in range(0, HEIGHT, HEIGHT // 8):
-        _, _, st = scene.render(cam, spp=1, depth=DEPTH, seed=SEED, traverse=ob.TRAVERSE_TREE, sampler=ob.SAMPLER_REFERENCE,
-                                threads=threads, rows=(r, r + 1))
-        cal_paths += st["paths"]
-        cal_segs += st["segments"]
-    rate = cal_paths / max(time.time() - t0, 1e-6)
-    want_paths = rate * budget_s
-    spp = max(1, min(4, int(want_paths // (WIDTH * HEIGHT))))
-    n_rows = int(min(HEIGHT, max(8, want_paths // (WIDTH * spp))))
-    step = HEIGHT / n_rows
-    paths = segs = 0
-    secs = 0.0
-    for k in range(n_rows):  # rows spread evenly over the frame so sky and ground are both sampled
-        r = int(k * step)
+    def run(stride, spp, th):
         _, _, st = scene.render(cam, spp=spp, depth=DEPTH, seed=SEED, traverse=ob.TRAVERSE_TREE, sampler=ob.SAMPLER_REFERENCE,
-                                threads=threads, rows=(r, r + 1))
-        paths += st["paths"]
-        segs += st["segments"]
-        secs += st["seconds"]
-    # one thread, as the reference runs (src/lib.rs:166-168), on a smaller sample
-    p1 = s1 = 0
-    t1 = 0.0
-    for k in range(max(2, n_rows // (4 * threads))):
-        r = int(k * HEIGHT / max(2, n_rows // (4 * threads)))
-        _, _, st = scene.render(cam, spp=spp, depth=DEPTH, seed=SEED, traverse=ob.TRAVERSE_TREE, sampler=ob.SAMPLER_REFERENCE,
-                                threads=1, rows=(r, r + 1))
-        p1 += st["paths"]
-        t1 += st["seconds"]
+                                threads=th, rows=(stride // 2, HEIGHT), row_stride=stride)
+        return st
+
+    # calibrate on every 64th row, then size the sample (rows spread evenly over the frame, so sky and
+    # ground are both in it) for the time budget
+    cal = run(16, 1, threads)
+    rate = cal["paths"] / max(cal["seconds"], 1e-6)
+    want_rows = max(16.0, rate * budget_s / WIDTH)
+    spp = int(max(1, min(8, want_rows // HEIGHT)))
+    stride = int(max(1, HEIGHT // max(1.0, want_rows / spp)))
+    st = run(stride, spp, threads)
+    paths, segs, secs, n_rows = st["paths"], st["segments"], st["seconds"], st["paths"] // (WIDTH * spp)
+    # one thread, as the reference runs (src/lib.rs:166-168), on a sample `threads` times smaller
+    st1 = run(min(HEIGHT // 4, stride * threads), spp, 1)
+    p1, t1 = st1["paths"], st1["seconds"]
     return {
         "value": round(paths / secs / 1e6, 4), "unit": "Mpaths/s", "cores": threads, "kind": "port",
         "sample": "%d rows of %dx%d spread over the frame at %d spp, depth %d: %d paths in %.1f s; reference-style tree + rejection sampling, f64"
@@ -76,6 +61,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--kernel-flags", type=int, default=0, help="RT_RENDER_KERNEL_* measurement aids (A/B runs)")
     args = ap.parse_args()
 
     import torch
@@ -109,7 +95,7 @@ def main():
         stream = torch.cuda.current_stream().cuda_stream
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-        scene.render_device(cam, d_sum.data_ptr(), begin, end, DEPTH, SEED, stream=stream)
+        scene.render_device(cam, d_sum.data_ptr(), begin, end, DEPTH, SEED, stream=stream, flags=args.kernel_flags)
         ev1.record()
         if world > 1:
             dist.reduce(d_sum, dst=0, op=dist.ReduceOp.SUM)

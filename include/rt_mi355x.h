@@ -101,7 +101,12 @@ typedef struct rt_render_opts {
     uint32_t flags;        /* RT_RENDER_* */
     uint64_t seed;         /* Philox4x32-10 key; counter = (pixel, sample, bounce, attempt) */
 } rt_render_opts;
-enum { RT_RENDER_ACCUMULATE = 1 /* add to the buffer instead of overwriting it */ };
+enum {
+    RT_RENDER_ACCUMULATE = 1,          /* add to the buffer instead of overwriting it */
+    RT_RENDER_KERNEL_LOCKSTEP = 2,     /* measurement aid: the plain one-segment-per-turn kernel */
+    RT_RENDER_KERNEL_NO_LDS_SCENE = 4, /* measurement aid: keep the BVH in HBM even when it would fit in LDS */
+    RT_RENDER_STATS = 8                /* measurement aid: instrumented kernel, see rt_debug_render_stats */
+};
 
 const char* rt_last_error(void);
 
@@ -147,6 +152,11 @@ int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out);
  * asynchronous with respect to the host. */
 int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, float* d_sum_rgb,
                      void* stream);
+
+/* Measurement aid: phase counters of the last RT_RENDER_STATS render on this scene:
+ * {inner-node turns*64, lanes in them, leaf turns*64, lanes, shade turns*64, lanes shading or
+ * regenerating, lanes regenerating, descent-loop turns*64}.  Synchronises the device. */
+int rt_debug_render_stats(rt_scene* scene, uint64_t out[8]);
 
 /* (1/spp) * sum, then color_to_ppm (src/lib.rs:148-149, :186-192): device
  * buffers, n_pixels*3 channels. */

@@ -97,11 +97,12 @@ void orc_generate_primary(const Camera* cam, uint64_t seed, int sampler, uint32_
 // zero.  rgb8 (optional) = color_to_ppm((1/spp)*sum) with spp = sample_end -
 // sample_begin.  threads <= 1 runs the reference's single-threaded loop nest;
 // otherwise scanlines are spread over OpenMP threads (per-pixel results do not
-// depend on the thread count).  counters: box tests, shape tests, segments, paths.
+// depend on the thread count).  Only rows row_begin, row_begin + row_stride, ...
+// below row_end are rendered (a bounded sample of a large frame).  counters: box tests, shape tests, segments, paths.
 // Returns wall seconds of the render loop.
 double orc_render(const orc_scene* s, const Camera* cam, int traverse, int sampler, uint32_t sample_begin,
                   uint32_t sample_end, uint32_t depth, uint64_t seed, int threads, uint32_t row_begin,
-                  uint32_t row_end, double* sum_rgb, uint8_t* rgb8, uint64_t* counters) {
+                  uint32_t row_end, uint32_t row_stride, double* sum_rgb, uint8_t* rgb8, uint64_t* counters) {
     const uint32_t W = cam->horiz_res;
     const double inv_spp = 1.0 / double(sample_end - sample_begin);
     TraceCounters total;
@@ -116,7 +117,7 @@ double orc_render(const orc_scene* s, const Camera* cam, int traverse, int sampl
         std::vector<Candidate> scratch;
         TraceCounters ctr;
 #pragma omp for schedule(dynamic, 1)
-        for (long j = long(row_begin); j < long(row_end); ++j) {
+        for (long j = long(row_begin); j < long(row_end); j += long(row_stride ? row_stride : 1)) {
             for (uint32_t i = 0; i < W; ++i) {
                 uint32_t pixel = uint32_t(j) * W + i;
                 Color acc{0.0, 0.0, 0.0};

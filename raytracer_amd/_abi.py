@@ -17,7 +17,8 @@ RT_OK = 0
 RT_ERR_INVALID_ARGUMENT, RT_ERR_UNSUPPORTED, RT_ERR_DEVICE, RT_ERR_IO, RT_ERR_LIMIT = 1, 2, 3, 4, 5
 RT_SHAPE_SPHERE, RT_SHAPE_DISC = 0, 1
 RT_MAT_DIFFUSE, RT_MAT_METAL, RT_MAT_DIELECTRIC, RT_MAT_TEXTUREMAP, RT_MAT_EMITTER = 0, 1, 2, 3, 4
-RT_RENDER_ACCUMULATE = 1
+RT_RENDER_ACCUMULATE, RT_RENDER_KERNEL_LOCKSTEP, RT_RENDER_KERNEL_NO_LDS_SCENE = 1, 2, 4
+RT_RENDER_STATS = 8
 
 # rt_hittable as a numpy record (same layout as the C struct), so that a million
 # hittables are one array and not a million Python objects.
@@ -102,6 +103,7 @@ PROTOTYPES = {
     "rt_scene_destroy": (None, [_vp]),
     "rt_scene_get_info": (_i, [_vp, C.POINTER(rt_scene_info)]),
     "rt_render_device": (_i, [_vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts), _vp, _vp]),
+    "rt_debug_render_stats": (_i, [_vp, _vp]),
     "rt_finalize_device": (_i, [_vp, _vp, _sz, _u32, _vp, _vp]),
     "rt_render": (_i, [_vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts), _vp, _vp]),
     "rt_trace_primary": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp]),

@@ -164,18 +164,18 @@ class Scene:
         o.sample_begin, o.sample_end, o.depth, o.flags, o.seed = int(sample_begin), int(sample_end), int(depth), int(flags), int(seed)
         return o
 
-    def render(self, cam, spp, depth=REFERENCE_DEPTH, seed=0, sample_begin=0, want_sum=True, want_rgb8=True):
+    def render(self, cam, spp, depth=REFERENCE_DEPTH, seed=0, sample_begin=0, want_sum=True, want_rgb8=True, flags=0):
         """Host-buffer render: returns (sum_rgb float32 (H,W,3) or None, rgb8 (H,W,3) or None)."""
         H, W = cam.vert_res, cam.horiz_res
         s = np.zeros((H, W, 3), dtype=np.float32) if want_sum else None
         q = np.zeros((H, W, 3), dtype=np.uint8) if want_rgb8 else None
-        o = self.opts(sample_begin, sample_begin + spp, depth, seed)
+        o = self.opts(sample_begin, sample_begin + spp, depth, seed, flags)
         check(lib.rt_render(self.handle, C.byref(cam.c), C.byref(o), ptr(s), ptr(q)))
         return s, q
 
-    def render_device(self, cam, d_sum_ptr, sample_begin, sample_end, depth, seed, stream=None, accumulate=False):
+    def render_device(self, cam, d_sum_ptr, sample_begin, sample_end, depth, seed, stream=None, accumulate=False, flags=0):
         """Asynchronous render into device memory (d_sum_ptr: integer address of W*H*3 floats)."""
-        o = self.opts(sample_begin, sample_end, depth, seed, _abi.RT_RENDER_ACCUMULATE if accumulate else 0)
+        o = self.opts(sample_begin, sample_end, depth, seed, flags | (_abi.RT_RENDER_ACCUMULATE if accumulate else 0))
         check(lib.rt_render_device(self.handle, C.byref(cam.c), C.byref(o), C.c_void_p(d_sum_ptr), C.c_void_p(stream or 0)))
 
     def finalize_device(self, d_sum_ptr, n_pixels, spp_total, d_rgb8_ptr, stream=None):

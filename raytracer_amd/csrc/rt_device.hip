@@ -7,12 +7,15 @@
 //   * The sphere / disc tests and the hit point use the reference's own f64
 //     formulas in the reference's operation order (no FMA contraction), so the
 //     nearest-hit primitive and its parameter equal the f64 restatement's.
-//   * Shading (scatter directions, throughput, sky) runs in f32.
+//   * Shading (scatter directions, throughput, sky) runs in f32 with FMA
+//     contraction off, so every kernel that shades a path (render, per-path
+//     dumps) produces the same bits whatever code surrounds it.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "rt_internal.h"
@@ -69,6 +72,7 @@ struct RenderParams {
     uint32_t sample_begin, sample_end, depth, flags;
     uint32_t key0, key1;
     uint32_t n_pixels, tiles_x, tiles_y;
+    uint32_t trav_threshold, inner_threshold;  // schedule of render_kernel_ws
 };
 
 // ---------------------------------------------------------------- Philox
@@ -98,6 +102,7 @@ __device__ __forceinline__ void sincos_rev(float rev, float* s, float* c) {
 }
 // uniform on the unit sphere: same distribution as random_vec3 (src/materials.rs:150-157)
 __device__ __forceinline__ void unit_sphere(float u0, float u1, float* x, float* y, float* z) {
+#pragma clang fp contract(off)
     float zz = 1.0f - 2.0f * u0;
     float r = sqrtf(fmaxf(0.0f, 1.0f - zz * zz));
     float s, c;
@@ -272,6 +277,7 @@ struct Path {
 };
 
 __device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
+#pragma clang fp contract(off)
     float inv = rsqrtf(x * x + y * y + z * z);
     x *= inv; y *= inv; z *= inv;
 }
@@ -282,6 +288,7 @@ __device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
 // f32-normalised direction (|d|^2 = 1 + e, |e| ~ 1e-7) is rescaled in f64 by the
 // series of 1/sqrt(1 + e), which leaves |d| = 1 to f64 rounding.
 __device__ __forceinline__ void unit_f64(float x, float y, float z, double* X, double* Y, double* Z) {
+#pragma clang fp contract(off)
     const double a = double(x), b = double(y), c = double(z);
     const double e = (a * a + b * b + c * c) - 1.0;
     const double k = 1.0 - 0.5 * e + 0.375 * (e * e);
@@ -290,9 +297,9 @@ __device__ __forceinline__ void unit_f64(float x, float y, float z, double* X, d
 
 // src/camera.rs:49-78 + src/ray.rs:9-11 with the two rejection loops replaced
 // by direct draws of the same distributions (quarter disc, unit square).
-__device__ __forceinline__ void camera_ray(const CamDev& C, const RenderParams& P, uint32_t pixel, uint32_t sample,
-                                           float o[3], float d[3]) {
-    const uint4 r = philox4x32_10(pixel, sample, 0u, 0u, P.key0, P.key1);
+// r = Philox block (pixel, sample, 0, 0).
+__device__ __forceinline__ void camera_ray_from(const CamDev& C, uint32_t pixel, const uint4 r, float o[3], float d[3]) {
+#pragma clang fp contract(off)
     const float rad = sqrtf(u01(r.x));
     float s, c;
     sincos_rev(0.25f * u01(r.y), &s, &c);
@@ -308,19 +315,29 @@ __device__ __forceinline__ void camera_ray(const CamDev& C, const RenderParams& 
     normalize3(d[0], d[1], d[2]);
 }
 
-__device__ __forceinline__ void start_path(const CamDev& C, const RenderParams& P, uint32_t pixel, uint32_t sample,
-                                           Path& p) {
+__device__ __forceinline__ void camera_ray(const CamDev& C, const RenderParams& P, uint32_t pixel, uint32_t sample,
+                                           float o[3], float d[3]) {
+    camera_ray_from(C, pixel, philox4x32_10(pixel, sample, 0u, 0u, P.key0, P.key1), o, d);
+}
+
+__device__ __forceinline__ void start_path_from(const CamDev& C, uint32_t pixel, uint32_t sample, const uint4 r, Path& p) {
     float o[3], d[3];
-    camera_ray(C, P, pixel, sample, o, d);
+    camera_ray_from(C, pixel, r, o, d);
     p.ox = double(o[0]); p.oy = double(o[1]); p.oz = double(o[2]);
     unit_f64(d[0], d[1], d[2], &p.dx, &p.dy, &p.dz);
     p.tr = p.tg = p.tb = 1.0f;
     p.pixel = pixel; p.sample = sample; p.bounce = 1;
 }
 
+__device__ __forceinline__ void start_path(const CamDev& C, const RenderParams& P, uint32_t pixel, uint32_t sample,
+                                           Path& p) {
+    start_path_from(C, pixel, sample, philox4x32_10(pixel, sample, 0u, 0u, P.key0, P.key1), p);
+}
+
 // src/materials.rs:59-76 + :159-171 + src/lib.rs:194-200
 __device__ __forceinline__ void texture_albedo(const SceneDev& S, int32_t texmat, float lx, float ly, float lz, float* r,
                                                float* g, float* b) {
+#pragma clang fp contract(off)
     const TexMatDev& m = S.texmat[texmat];
     const TexImgDev img = S.teximg[m.tex];
     const float kPi = 3.14159265358979323846f;
@@ -337,12 +354,23 @@ __device__ __forceinline__ void texture_albedo(const SceneDev& S, int32_t texmat
     *b = float(px.z) / 255.0f;
 }
 
-// One segment of accel_raytrace / raytrace (src/lib.rs:93-131).  Returns true
-// when the path goes on; otherwise (Lr,Lg,Lb) is the value the reference returns.
-__device__ __forceinline__ bool advance(const SceneDev& S, const RenderParams& P, Path& p, int32_t* stk, float& Lr,
-                                        float& Lg, float& Lb, int32_t* hit_id = nullptr, double* hit_t = nullptr) {
-    const Best hit = closest_hit<false>(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, stk);
-    if (hit_id) { *hit_id = hit.k < 0 ? -1 : hit.id; *hit_t = hit.t; }
+// What the scatter step needs to know about the surface that was hit.
+struct Surf {
+    double hx, hy, hz;  // scatter_loc
+    float nx, ny, nz;   // normal_at
+    float ddn;          // dir . normal
+    float w;            // fuzz (metal) or refractive index (dielectric)
+    int32_t kind;
+};
+
+// First half of the loop body of src/lib.rs:93-131: everything that needs no random number.  Returns
+// true when the path scatters on (sf filled, throughput already multiplied by the albedo); false when
+// it ends here with the colour (Lr,Lg,Lb): a miss (sky), an emitter, or the depth limit.  At the depth
+// limit the reference still calls scatter and then drops the ray (src/lib.rs:105, :134); with a
+// counter-based RNG that call has no effect on anything, so it is not made.
+__device__ __forceinline__ bool hit_part(const SceneDev& S, const RenderParams& P, Path& p, const Best& hit, Surf& sf,
+                                         float& Lr, float& Lg, float& Lb) {
+#pragma clang fp contract(off)
     const float dxf = float(p.dx), dyf = float(p.dy), dzf = float(p.dz);
     if (hit.k < 0) {  // src/lib.rs:117-130
         const float t = 0.5f * (dyf + 1.0f);
@@ -352,74 +380,66 @@ __device__ __forceinline__ bool advance(const SceneDev& S, const RenderParams& P
         return false;
     }
     const int32_t k = hit.k;
-    double hx, hy, hz;  // scatter_loc = orig + t*dir (src/ray.rs:12-14)
-    {
-#pragma clang fp contract(off)
-        hx = p.ox + hit.t * p.dx;
-        hy = p.oy + hit.t * p.dy;
-        hz = p.oz + hit.t * p.dz;
-    }
-    float nx, ny, nz;     // normal_at
-    float lx, ly, lz;     // obj_relative_loc (src/lib.rs:106-113)
+    sf.hx = p.ox + hit.t * p.dx;  // scatter_loc = orig + t*dir (src/ray.rs:12-14)
+    sf.hy = p.oy + hit.t * p.dy;
+    sf.hz = p.oz + hit.t * p.dz;
+    float lx, ly, lz;  // obj_relative_loc (src/lib.rs:106-113)
     if (k < S.n_spheres) {
         const double4 s = S.sph[k];
-        const float rx = float(hx - s.x), ry = float(hy - s.y), rz = float(hz - s.z);
+        const float rx = float(sf.hx - s.x), ry = float(sf.hy - s.y), rz = float(sf.hz - s.z);
         const float inv_r = 1.0f / float(s.w);
-        nx = rx * inv_r; ny = ry * inv_r; nz = rz * inv_r;  // src/geometry.rs:123-125
+        sf.nx = rx * inv_r; sf.ny = ry * inv_r; sf.nz = rz * inv_r;  // src/geometry.rs:123-125
         lx = rx; ly = ry; lz = rz;
-        normalize3(lx, ly, lz);
     } else {
         const DiscDev& dd = S.discs[k - S.n_spheres];
-        nx = float(dd.nx); ny = float(dd.ny); nz = float(dd.nz);  // src/geometry.rs:141-143
-        lx = float(hx - dd.cx); ly = float(hy - dd.cy); lz = float(hz - dd.cz);
+        sf.nx = float(dd.nx); sf.ny = float(dd.ny); sf.nz = float(dd.nz);  // src/geometry.rs:141-143
+        lx = float(sf.hx - dd.cx); ly = float(sf.hy - dd.cy); lz = float(sf.hz - dd.cz);
     }
     const int32_t kind_word = S.kind[k];
-    const int32_t kind = kind_word & 0xff;
     const float4 m = S.mat[k];
-    const float ddn = dxf * nx + dyf * ny + dzf * nz;
-    if (kind == RT_MAT_EMITTER) {  // src/lib.rs:101-104: the throughput is dropped
-        const float c = fabsf(ddn);
+    sf.kind = kind_word & 0xff;
+    sf.w = m.w;
+    sf.ddn = dxf * sf.nx + dyf * sf.ny + dzf * sf.nz;
+    if (sf.kind == RT_MAT_EMITTER) {  // src/lib.rs:101-104: the throughput is dropped
+        const float c = fabsf(sf.ddn);
         Lr = m.x * c; Lg = m.y * c; Lb = m.z * c;
         return false;
     }
-    float sx, sy, sz;  // scattered direction before Ray::new normalises it
     float ar = m.x, ag = m.y, ab = m.z;
-    if (kind == RT_MAT_DIFFUSE || kind == RT_MAT_TEXTUREMAP) {  // src/materials.rs:82-85, :122-125
-        const uint4 r = philox4x32_10(p.pixel, p.sample, p.bounce, 0u, P.key0, P.key1);
-        float vx, vy, vz;
-        unit_sphere(u01(r.x), u01(r.y), &vx, &vy, &vz);
-        sx = nx + vx; sy = ny + vy; sz = nz + vz;
-        if (kind == RT_MAT_TEXTUREMAP) texture_albedo(S, kind_word >> 8, lx, ly, lz, &ar, &ag, &ab);
-    } else if (kind == RT_MAT_METAL) {  // src/materials.rs:86-95, fuzzify :141-148
-        const float rx = dxf - 2.0f * ddn * nx, ry = dyf - 2.0f * ddn * ny, rz = dzf - 2.0f * ddn * nz;
-        bool accepted = false;
-        sx = rx; sy = ry; sz = rz;
-        for (uint32_t attempt = 0; attempt < uint32_t(kFuzzMaxAttempts); ++attempt) {
-            const uint4 r = philox4x32_10(p.pixel, p.sample, p.bounce, attempt, P.key0, P.key1);
-            float vx, vy, vz;
-            unit_sphere(u01(r.x), u01(r.y), &vx, &vy, &vz);
-            sx = rx + m.w * vx; sy = ry + m.w * vy; sz = rz + m.w * vz;
-            if (sx * nx + sy * ny + sz * nz > 0.0f) { accepted = true; break; }
-        }
-        if (!accepted) {  // the reference would recurse without bound here
-            Lr = Lg = Lb = 0.0f;
-            return false;
-        }
-    } else {  // RT_MAT_DIELECTRIC, src/materials.rs:96-121
+    if (sf.kind == RT_MAT_DIELECTRIC) ar = ag = ab = 1.0f;  // src/materials.rs:56-58
+    if (sf.kind == RT_MAT_TEXTUREMAP) {
+        if (k < S.n_spheres) normalize3(lx, ly, lz);  // spheres: normalised, discs: as is (src/lib.rs:108-111)
+        texture_albedo(S, kind_word >> 8, lx, ly, lz, &ar, &ag, &ab);
+    }
+    p.tr *= ar; p.tg *= ag; p.tb *= ab;
+    if (p.bounce >= P.depth) {  // src/lib.rs:134: depth exhausted returns the throughput
+        Lr = p.tr; Lg = p.tg; Lb = p.tb;
+        return false;
+    }
+    return true;
+}
+
+// Second half: Material::scatter (src/materials.rs:80-130) + Ray::new.  r0 = Philox block
+// (pixel, sample, bounce, 0).  Returns false only when the bounded fuzz loop gives up.
+__device__ __forceinline__ bool scatter_part(const RenderParams& P, Path& p, const Surf& sf, const uint4 r0) {
+#pragma clang fp contract(off)
+    const float dxf = float(p.dx), dyf = float(p.dy), dzf = float(p.dz);
+    const float nx = sf.nx, ny = sf.ny, nz = sf.nz, ddn = sf.ddn;
+    float sx, sy, sz;  // scattered direction before Ray::new normalises it
+    if (sf.kind == RT_MAT_DIELECTRIC) {  // src/materials.rs:96-121
         const float inc_cos = ddn;
         const float px = dxf - inc_cos * nx, py = dyf - inc_cos * ny, pz = dzf - inc_cos * nz;
         const bool entering = __float_as_uint(inc_cos) >> 31;  // signum < 0 (also for -0.0)
-        const float ratio = entering ? 1.0f / m.w : m.w;
+        const float ratio = entering ? 1.0f / sf.w : sf.w;
         const float qx = ratio * px, qy = ratio * py, qz = ratio * pz;
         const float sin2 = qx * qx + qy * qy + qz * qz;
         bool reflect = sin2 > 1.0f;
-        if (!reflect) {  // the Schlick draw happens only when sin2 <= 1 (`||` short-circuits)
-            const uint4 r = philox4x32_10(p.pixel, p.sample, p.bounce, 0u, P.key0, P.key1);
-            float r0 = (1.0f - ratio) / (1.0f + ratio);
-            r0 = r0 * r0;
+        if (!reflect) {  // the Schlick draw counts only when sin2 <= 1 (`||` short-circuits)
+            float r0f = (1.0f - ratio) / (1.0f + ratio);
+            r0f = r0f * r0f;
             const float x = 1.0f - fabsf(inc_cos);
-            const float reflectance = r0 + (1.0f - r0) * (x * x * x * x * x);
-            reflect = u01(r.z) < reflectance;
+            const float reflectance = r0f + (1.0f - r0f) * (x * x * x * x * x);
+            reflect = u01(r0.z) < reflectance;
         }
         if (reflect) {
             sx = px - inc_cos * nx; sy = py - inc_cos * ny; sz = pz - inc_cos * nz;
@@ -427,17 +447,43 @@ __device__ __forceinline__ bool advance(const SceneDev& S, const RenderParams& P
             const float sc_cos = (entering ? -1.0f : 1.0f) * sqrtf(1.0f - sin2);
             sx = qx + sc_cos * nx; sy = qy + sc_cos * ny; sz = qz + sc_cos * nz;
         }
-        ar = ag = ab = 1.0f;  // src/materials.rs:56-58
+    } else {
+        float vx, vy, vz;
+        unit_sphere(u01(r0.x), u01(r0.y), &vx, &vy, &vz);
+        if (sf.kind == RT_MAT_METAL) {  // src/materials.rs:86-95, fuzzify :141-148
+            const float rx = dxf - 2.0f * ddn * nx, ry = dyf - 2.0f * ddn * ny, rz = dzf - 2.0f * ddn * nz;
+            sx = rx + sf.w * vx; sy = ry + sf.w * vy; sz = rz + sf.w * vz;
+            uint32_t attempt = 1;
+            while (!(sx * nx + sy * ny + sz * nz > 0.0f)) {
+                if (attempt >= uint32_t(kFuzzMaxAttempts)) return false;  // the reference would recurse without bound
+                const uint4 r = philox4x32_10(p.pixel, p.sample, p.bounce, attempt, P.key0, P.key1);
+                unit_sphere(u01(r.x), u01(r.y), &vx, &vy, &vz);
+                sx = rx + sf.w * vx; sy = ry + sf.w * vy; sz = rz + sf.w * vz;
+                ++attempt;
+            }
+        } else {  // Diffuse and TextureMap, src/materials.rs:82-85, :122-125
+            sx = nx + vx; sy = ny + vy; sz = nz + vz;
+        }
     }
     normalize3(sx, sy, sz);  // Ray::new
-    p.tr *= ar; p.tg *= ag; p.tb *= ab;
-    p.ox = hx; p.oy = hy; p.oz = hz;
+    p.ox = sf.hx; p.oy = sf.hy; p.oz = sf.hz;
     unit_f64(sx, sy, sz, &p.dx, &p.dy, &p.dz);
-    if (p.bounce >= P.depth) {  // src/lib.rs:134: depth exhausted returns the throughput
-        Lr = p.tr; Lg = p.tg; Lb = p.tb;
+    ++p.bounce;
+    return true;
+}
+
+// One segment of accel_raytrace / raytrace (src/lib.rs:93-131).  Returns true
+// when the path goes on; otherwise (Lr,Lg,Lb) is the value the reference returns.
+__device__ __forceinline__ bool advance(const SceneDev& S, const RenderParams& P, Path& p, int32_t* stk, float& Lr,
+                                        float& Lg, float& Lb, int32_t* hit_id = nullptr, double* hit_t = nullptr) {
+    const Best hit = closest_hit<false>(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, stk);
+    if (hit_id) { *hit_id = hit.k < 0 ? -1 : hit.id; *hit_t = hit.t; }
+    Surf sf;
+    if (!hit_part(S, P, p, hit, sf, Lr, Lg, Lb)) return false;
+    if (!scatter_part(P, p, sf, philox4x32_10(p.pixel, p.sample, p.bounce, 0u, P.key0, P.key1))) {
+        Lr = Lg = Lb = 0.0f;
         return false;
     }
-    ++p.bounce;
     return true;
 }
 
@@ -505,6 +551,273 @@ __global__ __launch_bounds__(kBlock) void render_kernel(SceneDev S, CamDev C, Re
                 alive = false;
             }
         }
+    }
+}
+
+// ------------------------------------------------ wave-scheduled render kernel
+// Same work assignment and arithmetic as render_kernel, different schedule.  A
+// lane no longer walks "traverse, then shade" in lock step with its wave:
+//   * a wave keeps stepping its BVH descents while at least kTravThreshold lanes
+//     are still descending; lanes that finished wait for the shade phase;
+//   * inside that, inner-node steps (f32) run until fewer than kInnerThreshold
+//     lanes sit on an inner node, then every lane parked on a leaf runs the f64
+//     sphere test together;
+//   * the shade phase scatters / terminates / regenerates all waiting lanes at
+//     once and sends them back into the descent.
+// With LDS16 the whole scene is staged in LDS: boxes as f16 (rounded outward, so
+// the descent stays conservative), child links as int16, spheres as f64.
+constexpr int kTravThreshold = 8;
+constexpr int kInnerThreshold = 2;
+
+struct Node16 {       // 32 bytes: two 16-byte LDS reads
+    uint16_t h[12];   // lo0.xyz hi0.xyz lo1.xyz hi1.xyz as IEEE half bits
+    int16_t child0, child1;
+    uint32_t pad;
+};
+static_assert(sizeof(Node16) == 32, "Node16 must be 32 bytes");
+
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+struct Trav {
+    float inv[3], A[3], B[3];
+    float tmax;
+    int32_t node;
+    int32_t sp;
+    Best best;
+};
+
+__device__ __forceinline__ void trav_begin(const SceneDev& S, const Path& p, Trav& T) {
+    T.best.t = 0.0;
+    T.best.k = -1;
+    T.best.id = 0x7fffffff;
+    T.sp = 0;
+    for (int32_t i = 0; i < S.n_discs; ++i) {
+        double t;
+        if (disc_intersect_f64(S.discs[i], p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, &t))
+            consider(T.best, t, S.n_spheres + i, S.prim_id[S.n_spheres + i]);
+    }
+    const bool skip = (S.n_nodes == 0) || (T.best.k >= 0 && T.best.t <= 0.0);
+    T.node = skip ? kLeafSentinel : 0;
+    const float of[3] = {float(p.ox), float(p.oy), float(p.oz)};
+    const float df[3] = {float(p.dx), float(p.dy), float(p.dz)};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float d = df[a];
+        const float i = (fabsf(d) >= 1.0e-18f) ? __frcp_rn(d) : copysignf(1.0e18f, d);
+        T.inv[a] = i;
+        T.A[a] = -(of[a] + S.eps) * i;
+        T.B[a] = -(of[a] - S.eps) * i;
+    }
+    T.tmax = (T.best.k >= 0) ? float(T.best.t) * (1.0f + 4.0e-7f) : 3.0e38f;
+}
+
+__device__ __forceinline__ void slab2(const Trav& T, float lo0x, float lo0y, float lo0z, float hi0x, float hi0y,
+                                      float hi0z, float lo1x, float lo1y, float lo1z, float hi1x, float hi1y,
+                                      float hi1z, float* en0, float* ex0, float* en1, float* ex1) {
+    const float t0x = fmaf(lo0x, T.inv[0], T.A[0]), t1x = fmaf(hi0x, T.inv[0], T.B[0]);
+    const float t0y = fmaf(lo0y, T.inv[1], T.A[1]), t1y = fmaf(hi0y, T.inv[1], T.B[1]);
+    const float t0z = fmaf(lo0z, T.inv[2], T.A[2]), t1z = fmaf(hi0z, T.inv[2], T.B[2]);
+    *en0 = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
+    *ex0 = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), T.tmax));
+    const float u0x = fmaf(lo1x, T.inv[0], T.A[0]), u1x = fmaf(hi1x, T.inv[0], T.B[0]);
+    const float u0y = fmaf(lo1y, T.inv[1], T.A[1]), u1y = fmaf(hi1y, T.inv[1], T.B[1]);
+    const float u0z = fmaf(lo1z, T.inv[2], T.A[2]), u1z = fmaf(hi1z, T.inv[2], T.B[2]);
+    *en1 = fmaxf(fmaxf(fminf(u0x, u1x), fminf(u0y, u1y)), fmaxf(fminf(u0z, u1z), 0.0f));
+    *ex1 = fminf(fminf(fmaxf(u0x, u1x), fmaxf(u0y, u1y)), fminf(fmaxf(u0z, u1z), T.tmax));
+}
+
+template <int BLOCK>
+__device__ __forceinline__ void descend(Trav& T, float en0, float ex0, float en1, float ex1, int32_t c0, int32_t c1,
+                                        int32_t* stk) {
+    const bool h0 = en0 <= ex0, h1 = en1 <= ex1;
+    if (h0 && h1) {
+        const bool swap = en1 < en0;
+        stk[T.sp * BLOCK] = swap ? c0 : c1;
+        ++T.sp;
+        T.node = swap ? c1 : c0;
+    } else if (h0) {
+        T.node = c0;
+    } else if (h1) {
+        T.node = c1;
+    } else if (T.sp > 0) {
+        --T.sp;
+        T.node = stk[T.sp * BLOCK];
+    } else {
+        T.node = kLeafSentinel;
+    }
+}
+
+template <bool LDS16, int BLOCK>
+__device__ __forceinline__ void inner_step(const SceneDev& S, const uint4* lds_q0, const uint4* lds_q1, Trav& T,
+                                           int32_t* stk) {
+    float en0, ex0, en1, ex1;
+    int32_t c0, c1;
+    if (LDS16) {
+        const uint4 a = lds_q0[T.node], b = lds_q1[T.node];
+        const half2_t h0 = __builtin_bit_cast(half2_t, a.x), h1 = __builtin_bit_cast(half2_t, a.y);
+        const half2_t h2 = __builtin_bit_cast(half2_t, a.z), h3 = __builtin_bit_cast(half2_t, a.w);
+        const half2_t h4 = __builtin_bit_cast(half2_t, b.x), h5 = __builtin_bit_cast(half2_t, b.y);
+        // h0 = lo0.xy  h1 = lo0.z hi0.x  h2 = hi0.yz  h3 = lo1.xy  h4 = lo1.z hi1.x  h5 = hi1.yz
+        slab2(T, float(h0.x), float(h0.y), float(h1.x), float(h1.y), float(h2.x), float(h2.y), float(h3.x), float(h3.y),
+              float(h4.x), float(h4.y), float(h5.x), float(h5.y), &en0, &ex0, &en1, &ex1);
+        c0 = int32_t(int16_t(b.z & 0xffffu));
+        c1 = int32_t(b.z) >> 16;
+    } else {
+        const float4* q = reinterpret_cast<const float4*>(S.nodes + T.node);
+        const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        slab2(T, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, &en0, &ex0, &en1, &ex1);
+        c0 = __float_as_int(q3.x);
+        c1 = __float_as_int(q3.y);
+    }
+    descend<BLOCK>(T, en0, ex0, en1, ex1, c0, c1, stk);
+}
+
+template <bool LDS16, int BLOCK>
+__device__ __forceinline__ void leaf_step(const SceneDev& S, const double4* lds_sph, const Path& p, Trav& T, int32_t* stk) {
+    const int32_t k = ~T.node;
+    const double4 s = LDS16 ? lds_sph[k] : S.sph[k];
+    double t;
+    if (sphere_intersect_f64(s.x, s.y, s.z, s.w, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, &t)) {
+        consider(T.best, t, k, S.prim_id[k]);
+        T.tmax = float(T.best.t) * (1.0f + 4.0e-7f);
+    }
+    if (T.sp > 0) {
+        --T.sp;
+        T.node = stk[T.sp * BLOCK];
+    } else {
+        T.node = kLeafSentinel;
+    }
+}
+
+// STATS (diagnostic build only): counts, per phase, wave-level turns and the lanes that took part, into
+// work_counter[8..15] = {inner turns*64, inner lanes, leaf turns*64, leaf lanes, shade turns*64, shading
+// lanes, lanes that regenerated, descent-loop turns*64}.
+template <bool LDS16, int BLOCK, bool STATS>
+__global__ __launch_bounds__(BLOCK) void render_kernel_ws(SceneDev S, CamDev C, RenderParams P,
+                                                          const Node16* __restrict__ nodes16, uint32_t stack_depth,
+                                                          float* __restrict__ sum_rgb, uint32_t* __restrict__ work_counter) {
+    uint32_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    extern __shared__ uint4 lds_raw[];
+    // LDS layout (16-byte units): [q0: n_nodes][q1: n_nodes][spheres: 2*n_spheres][stack: stack_depth*BLOCK/4]
+    uint4* lds_q0 = lds_raw;
+    uint4* lds_q1 = lds_raw + (LDS16 ? S.n_nodes : 0);
+    double4* lds_sph = reinterpret_cast<double4*>(lds_raw + (LDS16 ? 2 * S.n_nodes : 0));
+    int32_t* stk = reinterpret_cast<int32_t*>(lds_raw + (LDS16 ? 2 * S.n_nodes + 2 * S.n_spheres : 0)) + threadIdx.x;
+    (void)stack_depth;
+    if (LDS16) {
+        const uint4* src = reinterpret_cast<const uint4*>(nodes16);
+        for (int32_t i = threadIdx.x; i < S.n_nodes; i += BLOCK) { lds_q0[i] = src[2 * i]; lds_q1[i] = src[2 * i + 1]; }
+        const uint4* ssrc = reinterpret_cast<const uint4*>(S.sph);
+        uint4* sdst = reinterpret_cast<uint4*>(lds_sph);
+        for (int32_t i = threadIdx.x; i < 2 * S.n_spheres; i += BLOCK) sdst[i] = ssrc[i];
+        __syncthreads();
+    }
+
+    Path p;
+    p.ox = p.oy = p.oz = 0.0;
+    p.dx = p.dy = p.dz = 0.0;
+    p.tr = p.tg = p.tb = 0.0f;
+    p.pixel = 0; p.sample = 0; p.bounce = 0;
+    Trav T;
+    T.node = kLeafSentinel;
+    T.sp = 0;
+    T.tmax = 0.0f;
+    T.best.t = 0.0; T.best.k = -1; T.best.id = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { T.inv[a] = 0.0f; T.A[a] = 0.0f; T.B[a] = 0.0f; }
+    bool have_pixel = false, alive = false, done = false;
+    uint32_t next_sample = 0;
+    float ar = 0.0f, ag = 0.0f, ab = 0.0f;
+    const uint32_t n_work = P.tiles_x * P.tiles_y * 64u;
+    const int trav_threshold = int(P.trav_threshold), inner_threshold = int(P.inner_threshold);
+
+    for (;;) {
+        // ---- shade phase: every lane that is not descending.  One Philox block per lane and turn:
+        // a path that scatters on draws (pixel, sample, bounce, 0), a path that ends makes room for
+        // the pixel's next sample, whose camera ray draws (pixel, sample, 0, 0).
+        if (STATS) st[4]++;
+        if (T.node == kLeafSentinel && !done) {
+            if (STATS) { st[5]++; if (!alive) st[6]++; }
+            Surf sf;
+            bool fresh = false;
+            if (alive) {
+                float Lr, Lg, Lb;
+                if (!hit_part(S, P, p, T.best, sf, Lr, Lg, Lb)) {
+                    ar += Lr; ag += Lg; ab += Lb;
+                    alive = false;
+                }
+            }
+            if (!alive) {
+                if (have_pixel && next_sample >= P.sample_end) {
+                    float* out = sum_rgb + 3 * size_t(p.pixel);
+                    if (P.flags & RT_RENDER_ACCUMULATE) { ar += out[0]; ag += out[1]; ab += out[2]; }
+                    out[0] = ar; out[1] = ag; out[2] = ab;
+                    have_pixel = false;
+                }
+                if (!have_pixel) {
+                    const uint32_t w = atomicAdd(work_counter, 1u);
+                    if (w >= n_work) {
+                        done = true;
+                    } else {
+                        const uint32_t tile = w >> 6, in_tile = w & 63u;
+                        const uint32_t x = (tile % P.tiles_x) * 8u + (in_tile & 7u);
+                        const uint32_t y = (tile / P.tiles_x) * 8u + (in_tile >> 3);
+                        if (x < C.W && y < C.H) {
+                            have_pixel = true;
+                            p.pixel = y * C.W + x;
+                            next_sample = P.sample_begin;
+                            ar = ag = ab = 0.0f;
+                        }
+                    }
+                }
+                if (have_pixel && next_sample < P.sample_end) {
+                    if (P.depth == 0) {
+                        ar += 1.0f; ag += 1.0f; ab += 1.0f;
+                    } else {
+                        p.sample = next_sample;
+                        fresh = true;
+                        alive = true;
+                    }
+                    ++next_sample;
+                }
+            }
+            if (alive) {
+                const uint4 r = philox4x32_10(p.pixel, p.sample, fresh ? 0u : p.bounce, 0u, P.key0, P.key1);
+                if (fresh) {
+                    start_path_from(C, p.pixel, p.sample, r, p);
+                } else if (!scatter_part(P, p, sf, r)) {
+                    alive = false;  // bounded fuzz loop gave up: the path contributes nothing
+                }
+                if (alive) trav_begin(S, p, T);
+            }
+        }
+        if (__all(done)) break;
+
+        // ---- descent phase
+        for (;;) {
+            const bool descending = T.node != kLeafSentinel;
+            const int n_desc = int(__popcll(__ballot(descending)));
+            const bool someone_waits = __any(!descending && !done);
+            if (n_desc == 0 || (n_desc < trav_threshold && someone_waits)) break;
+            if (STATS) st[7]++;
+            while (int(__popcll(__ballot(T.node >= 0))) >= inner_threshold) {
+                if (STATS) { st[0]++; if (T.node >= 0) st[1]++; }
+                if (T.node >= 0) inner_step<LDS16, BLOCK>(S, lds_q0, lds_q1, T, stk);
+            }
+            if (__any(T.node < 0 && T.node != kLeafSentinel)) {
+                if (STATS) { st[2]++; if (T.node < 0 && T.node != kLeafSentinel) st[3]++; }
+                if (T.node < 0 && T.node != kLeafSentinel) leaf_step<LDS16, BLOCK>(S, lds_sph, p, T, stk);
+            } else {
+                // fewer than kInnerThreshold lanes on inner nodes and nobody on a leaf: step them anyway
+                if (STATS) { st[0]++; if (T.node >= 0) st[1]++; }
+                if (T.node >= 0) inner_step<LDS16, BLOCK>(S, lds_q0, lds_q1, T, stk);
+            }
+        }
+    }
+    if (STATS) {
+        unsigned long long* out = reinterpret_cast<unsigned long long*>(work_counter + 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) atomicAdd(out + i, (unsigned long long)st[i]);
     }
 }
 
@@ -617,12 +930,40 @@ struct rt_scene {
     SceneDev dev{};
     std::vector<void*> allocations;
     uint32_t* d_work_counter = nullptr;
+    const Node16* d_nodes16 = nullptr;  // f16 copy of the nodes for the LDS-resident kernel, or null
+    size_t lds16_scene_bytes = 0;
     uint32_t stack_depth = 0;
     int n_cu = 0;
     double bound_abs = 0.0;  // largest |coordinate| of any box corner
 };
 
 namespace {
+
+// IEEE half bits of the largest half <= x (down) or the smallest half >= x (up); overflow gives +-inf.
+uint16_t half_bits(_Float16 h) { uint16_t b; std::memcpy(&b, &h, 2); return b; }
+_Float16 half_from_bits(uint16_t b) { _Float16 h; std::memcpy(&h, &b, 2); return h; }
+uint16_t half_round_down(float x) {
+    _Float16 h = _Float16(x);
+    if (float(h) > x) {
+        uint16_t b = half_bits(h);
+        if ((b & 0x7fffu) == 0) b = 0x8001u;          // below zero: smallest negative subnormal
+        else if (b & 0x8000u) b = uint16_t(b + 1);    // negative: larger magnitude
+        else b = uint16_t(b - 1);                     // positive (incl. +inf -> 65504)
+        h = half_from_bits(b);
+    }
+    return half_bits(h);
+}
+uint16_t half_round_up(float x) {
+    _Float16 h = _Float16(x);
+    if (float(h) < x) {
+        uint16_t b = half_bits(h);
+        if ((b & 0x7fffu) == 0) b = 0x0001u;
+        else if (b & 0x8000u) b = uint16_t(b - 1);    // negative (incl. -inf -> -65504)
+        else b = uint16_t(b + 1);
+        h = half_from_bits(b);
+    }
+    return half_bits(h);
+}
 
 template <class T>
 int upload(rt_scene* sc, const std::vector<T>& host, const T** dev_ptr) {
@@ -688,6 +1029,10 @@ RenderParams make_params(const rt_camera& cam, const rt_render_opts& o) {
     P.n_pixels = cam.horiz_res * cam.vert_res;
     P.tiles_x = (cam.horiz_res + 7) / 8;
     P.tiles_y = (cam.vert_res + 7) / 8;
+    P.trav_threshold = kTravThreshold;
+    P.inner_threshold = kInnerThreshold;
+    if (const char* e = std::getenv("RT_TRAV_THRESHOLD")) P.trav_threshold = uint32_t(std::atoi(e));    // tuning aid
+    if (const char* e = std::getenv("RT_INNER_THRESHOLD")) P.inner_threshold = uint32_t(std::max(1, std::atoi(e)));
     return P;
 }
 
@@ -828,6 +1173,25 @@ int rt_scene_create(const rt_hittable* hittables, size_t n_hittables, const rt_t
     }
 
     int rc;
+    // f16 copy of the nodes for the LDS-resident kernel: small scenes only (int16 child links, LDS capacity)
+    {
+        const size_t scene_bytes = 32 * bvh.nodes.size() + 32 * n_s;
+        const size_t with_stack = scene_bytes + size_t(sc->stack_depth) * 512 * sizeof(int32_t);
+        if (n_s > 0 && n_s <= 32767 && bvh.nodes.size() <= 32767 && with_stack <= 80 * 1024) {
+            std::vector<Node16> n16(bvh.nodes.size());
+            for (size_t i = 0; i < bvh.nodes.size(); ++i) {
+                const Node& nd = bvh.nodes[i];
+                for (int a = 0; a < 3; ++a) {
+                    n16[i].h[a] = half_round_down(nd.lo0[a]); n16[i].h[3 + a] = half_round_up(nd.hi0[a]);
+                    n16[i].h[6 + a] = half_round_down(nd.lo1[a]); n16[i].h[9 + a] = half_round_up(nd.hi1[a]);
+                }
+                n16[i].child0 = int16_t(nd.child0); n16[i].child1 = int16_t(nd.child1);
+                n16[i].pad = 0;
+            }
+            if ((rc = upload(sc, n16, &sc->d_nodes16)) != RT_OK) return bail(rc);
+            sc->lds16_scene_bytes = scene_bytes;
+        }
+    }
     if ((rc = upload(sc, bvh.nodes, &sc->dev.nodes)) != RT_OK) return bail(rc);
     if ((rc = upload(sc, h_sph, &sc->dev.sph)) != RT_OK) return bail(rc);
     if ((rc = upload(sc, h_disc, &sc->dev.discs)) != RT_OK) return bail(rc);
@@ -856,7 +1220,7 @@ int rt_scene_create(const rt_hittable* hittables, size_t n_hittables, const rt_t
     sc->info.bvh_depth = bvh.depth;
     sc->info.stack_depth = sc->stack_depth;
     sc->info.device = device;
-    sc->info.lds_resident = 0;
+    sc->info.lds_resident = sc->d_nodes16 ? 1 : 0;
     sc->info.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     *out = sc;
     return RT_OK;
@@ -878,16 +1242,41 @@ int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_render_opts
     S.eps = descent_eps(scene, camera_abs(*cam));
     const CamDev C = make_cam(*cam);
     const RenderParams P = make_params(*cam, *opts);
-    const size_t lds = stack_bytes(scene);
-    int per_cu = 0;
-    RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel, kBlock, lds));
-    if (per_cu < 1) per_cu = 1;
     const uint64_t n_work = uint64_t(P.tiles_x) * P.tiles_y * 64u;
-    uint64_t blocks = uint64_t(scene->n_cu) * uint64_t(per_cu);
-    blocks = std::min<uint64_t>(blocks, (n_work + kBlock - 1) / kBlock);
-    RT_HIP(hipMemsetAsync(scene->d_work_counter, 0, sizeof(uint32_t), st));
-    hipLaunchKernelGGL(render_kernel, dim3(uint32_t(blocks)), dim3(kBlock), lds, st, S, C, P, d_sum_rgb, scene->d_work_counter);
+    RT_HIP(hipMemsetAsync(scene->d_work_counter, 0, 256, st));
+    auto grid_for = [&](int per_cu, int block) {
+        uint64_t blocks = uint64_t(scene->n_cu) * uint64_t(per_cu < 1 ? 1 : per_cu);
+        return dim3(uint32_t(std::min<uint64_t>(blocks, (n_work + block - 1) / block)));
+    };
+    int per_cu = 0;
+    if (opts->flags & RT_RENDER_KERNEL_LOCKSTEP) {
+        const size_t lds = stack_bytes(scene);
+        RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel, kBlock, lds));
+        hipLaunchKernelGGL(render_kernel, grid_for(per_cu, kBlock), dim3(kBlock), lds, st, S, C, P, d_sum_rgb, scene->d_work_counter);
+    } else if (scene->d_nodes16 && !(opts->flags & RT_RENDER_KERNEL_NO_LDS_SCENE)) {
+        constexpr int B = 512;
+        const size_t lds = scene->lds16_scene_bytes + size_t(std::max<uint32_t>(scene->stack_depth, 1u)) * B * sizeof(int32_t);
+        auto k = (opts->flags & RT_RENDER_STATS) ? render_kernel_ws<true, B, true> : render_kernel_ws<true, B, false>;
+        RT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, B, lds));
+        hipLaunchKernelGGL(k, grid_for(per_cu, B), dim3(B), lds, st, S, C, P, scene->d_nodes16, scene->stack_depth, d_sum_rgb,
+                           scene->d_work_counter);
+    } else {
+        const size_t lds = stack_bytes(scene);
+        auto k = (opts->flags & RT_RENDER_STATS) ? render_kernel_ws<false, kBlock, true> : render_kernel_ws<false, kBlock, false>;
+        RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, kBlock, lds));
+        hipLaunchKernelGGL(k, grid_for(per_cu, kBlock), dim3(kBlock), lds, st, S, C, P, static_cast<const Node16*>(nullptr),
+                           scene->stack_depth, d_sum_rgb, scene->d_work_counter);
+    }
     RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_debug_render_stats(rt_scene* scene, uint64_t out[8]) {
+    if (!scene || !out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_render_stats: null argument");
+    RT_HIP(hipSetDevice(scene->device));
+    RT_HIP(hipDeviceSynchronize());
+    RT_HIP(hipMemcpy(out, scene->d_work_counter + 8, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

@@ -68,7 +68,7 @@ def lib():
         L.orc_trace.argtypes = [vp, i, vp, vp, sz, vp, vp, vp, vp]
         L.orc_generate_primary.argtypes = [C.POINTER(Camera), u64, i, u32, u32, u32, u32, vp, vp]
         L.orc_render.restype = d
-        L.orc_render.argtypes = [vp, C.POINTER(Camera), i, i, u32, u32, u32, u64, i, u32, u32, vp, vp, vp]
+        L.orc_render.argtypes = [vp, C.POINTER(Camera), i, i, u32, u32, u32, u64, i, u32, u32, u32, vp, vp, vp]
         L.orc_trace_paths.argtypes = [vp, C.POINTER(Camera), i, i, vp, vp, sz, u32, u64, vp, vp]
         L.orc_path_segments.argtypes = [vp, C.POINTER(Camera), i, i, vp, vp, sz, u32, u64, u32, vp, vp, vp]
         L.orc_finalize.argtypes = [vp, sz, d, vp]
@@ -153,7 +153,7 @@ class Scene:
         return ids, t, nrm, ctr
 
     def render(self, cam, spp, depth=10, seed=0, traverse=TRAVERSE_GATED_BRUTE, sampler=SAMPLER_DIRECT, sample_begin=0,
-               threads=0, rows=None):
+               threads=0, rows=None, row_stride=1):
         H, W = cam.vert_res, cam.horiz_res
         s = np.zeros((H, W, 3))
         q = np.zeros((H, W, 3), dtype=np.uint8)
@@ -163,7 +163,7 @@ class Scene:
         r0, r1 = rows if rows else (0, H)
         th = threads if threads else lib().orc_max_threads()
         secs = lib().orc_render(self.handle, C.byref(cam), traverse, sampler, sample_begin, sample_begin + spp, depth, seed, th,
-                                r0, r1, s.ctypes.data, q.ctypes.data, ctr.ctypes.data)
+                                r0, r1, row_stride, s.ctypes.data, q.ctypes.data, ctr.ctypes.data)
         return s, q, {"seconds": secs, "box_tests": int(ctr[0]), "shape_tests": int(ctr[1]), "segments": int(ctr[2]), "paths": int(ctr[3]), "threads": th}
 
     def trace_paths(self, cam, pixel, sample, depth=10, seed=0, traverse=TRAVERSE_GATED_BRUTE, sampler=SAMPLER_DIRECT,

@@ -192,6 +192,27 @@ def test_render_is_reproducible_and_ranges_add_up(scene1, rt):
     assert np.allclose(lo + hi, a, rtol=2e-6, atol=1e-6)  # 2 "virtual ranks" = 1 rank, up to f32 summation order
 
 
+def test_all_render_schedules_give_the_same_image(scene1, rt):
+    # lock-step kernel, wave-scheduled kernel with the BVH in HBM (f32 boxes) and in LDS (f16 boxes):
+    # the schedule and the box precision change which boxes are visited, never the hit that is found
+    from raytracer_amd import _abi
+
+    cam = rt.default_camera(200, 120)
+    assert scene1.info["lds_resident"] == 1
+    a, _ = scene1.render(cam, 6, depth=50, seed=8)
+    b, _ = scene1.render(cam, 6, depth=50, seed=8, flags=_abi.RT_RENDER_KERNEL_LOCKSTEP)
+    c, _ = scene1.render(cam, 6, depth=50, seed=8, flags=_abi.RT_RENDER_KERNEL_NO_LDS_SCENE)
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+    # and the image is the sum, in sample order, of the colours trace_paths returns path by path
+    px = np.repeat(np.arange(200 * 120, dtype=np.uint32), 6)
+    sm = np.tile(np.arange(6, dtype=np.uint32), 200 * 120)
+    cols = scene1.trace_paths(cam, px, sm, depth=50, seed=8).reshape(200 * 120, 6, 3)
+    acc = np.zeros((200 * 120, 3), dtype=np.float32)
+    for k in range(6):
+        acc += cols[:, k, :]
+    assert np.array_equal(acc.reshape(120, 200, 3), a)
+
+
 def test_finalize_matches_color_to_ppm(scene1, ob, rt):
     cam = rt.default_camera(64, 64)
     s, q = scene1.render(cam, 4, depth=10, seed=1)
