@@ -39,7 +39,7 @@ def cpu_baseline(hittables, budget_s):
     cal = run(16, 1, threads)
     rate = cal["paths"] / max(cal["seconds"], 1e-6)
     want_rows = max(16.0, rate * budget_s / WIDTH)
-    spp = int(max(1, min(8, want_rows // HEIGHT)))
+    spp = int(max(1, min(64, want_rows // HEIGHT)))
     stride = int(max(1, HEIGHT // max(1.0, want_rows / spp)))
     st = run(stride, spp, threads)
     paths, segs, secs, n_rows = st["paths"], st["segments"], st["seconds"], st["paths"] // (WIDTH * spp)

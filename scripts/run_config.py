@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Times one of the parity/stress configurations on cuda:0 and prints one JSON line.
+
+    python scripts/run_config.py c2|c2d10|c4|c5|c1 [--spp N] [--stats]
+
+c1 bundled scene.json 512x512 (disc + emitter + texture, linear path)   c2 random spheres 1080p depth 50
+c2d10 the same at the reference's depth 10    c4 earth + nested glass shells    c5 1M spheres 1080p 64 spp
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("config")
+    ap.add_argument("--spp", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--stats", action="store_true")
+    ap.add_argument("--flags", type=int, default=0)
+    a = ap.parse_args()
+    import numpy as np
+    import torch
+
+    import raytracer_amd as rt
+    from raytracer_amd import _abi, roofline
+
+    earth = np.load(os.path.join(ROOT, "tests", "golden", "earthmap_rgb8.npz"))["rgb8"]
+    t0 = time.time()
+    if a.config in ("c2", "c2d10"):
+        h, tex, cam, spp, depth = rt.gen_scene(1), [], rt.default_camera(1920, 1080), 100, (50 if a.config == "c2" else 10)
+    elif a.config == "c4":
+        h, tex, spp, depth = rt.gen_scene_shells(8), [earth], 100, 50
+        cam = rt.Camera.build([0, 0, 1], [0, 1.5, -5], 1.0, 0.1, 1920, 1080)
+    elif a.config == "c5":
+        h, tex, spp, depth = rt.gen_scene_grid(1, 1000), [], 64, 50
+        cam = rt.Camera.build([0, 0, 0], [130, 40, 30], 1.0, 0.1, 1920, 1080)
+    elif a.config == "c1":
+        cfg = rt.Config.from_json(os.path.join(ROOT, "tests", "golden", "scene.json"), texture_loader=lambda p: earth)
+        h, tex, cam, spp, depth = cfg.hittables, cfg.textures, cfg.camera, 10, 10
+    else:
+        raise SystemExit("unknown config")
+    gen_s = time.time() - t0
+    spp = a.spp or spp
+    scene = rt.Scene(h, tex)
+    info = scene.info
+    H, W = cam.vert_res, cam.horiz_res
+    d_sum = torch.zeros(H, W, 3, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    flags = a.flags | (_abi.RT_RENDER_STATS if a.stats else 0)
+    scene.render_device(cam, d_sum.data_ptr(), 0, spp, depth, 0, stream=stream, flags=flags)
+    torch.cuda.synchronize()
+    ms = []
+    for _ in range(a.steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        scene.render_device(cam, d_sum.data_ptr(), 0, spp, depth, 0, stream=stream, flags=flags)
+        e1.record()
+        torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    out = {"config": a.config, "n_hittables": int(info["n_hittables"]), "bvh_nodes": int(info["n_nodes"]), "bvh_depth": int(info["bvh_depth"]),
+           "lds_resident": int(info["lds_resident"]), "scene_device_MB": round(info["device_bytes"] / 1e6, 2),
+           "scene_build_s": round(info["build_seconds"], 3), "scene_gen_s": round(gen_s, 3), "width": W, "height": H, "spp": spp, "depth": depth,
+           "kernel_ms": round(min(ms), 3), "Mpaths_per_s": round(W * H * spp / min(ms) / 1e3, 1),
+           "image_mean": round(float(d_sum.mean().item()) / spp, 5)}
+    if a.stats:
+        st = np.zeros(8, dtype=np.uint64)
+        _abi.check(_abi.lib.rt_debug_render_stats(scene.handle, st.ctypes.data))
+        o = st.astype(float)
+        paths = W * H * spp
+        seg = o[5] / paths  # one shade-phase visit per segment (+ one per fresh path that needed none)
+        out["stats"] = {"inner_steps_per_path": round(o[1] / paths, 2), "leaf_tests_per_path": round(o[3] / paths, 2),
+                        "shade_visits_per_path": round(seg, 3), "inner_lane_util": round(o[1] / max(o[0], 1), 3),
+                        "leaf_lane_util": round(o[3] / max(o[2], 1), 3), "shade_lane_util": round(o[5] / max(o[4], 1), 3)}
+        out["algorithmic_bytes_per_segment"] = roofline.bytes_per_segment(len(h))
+        out["executed_node_bytes_per_path"] = round(o[1] / paths * 64 + o[3] / paths * 32, 1)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

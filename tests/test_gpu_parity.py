@@ -351,6 +351,53 @@ def test_full_size_properties_1080p(scene1, rt):
     assert np.array_equal(q, q2)
 
 
+def test_million_sphere_scene_primary_hits_and_render(rt, ob):
+    # the 1M-sphere stress configuration at full size: BVH in HBM (does not fit LDS), f32 boxes
+    h = rt.gen_scene_grid(1, 1000)
+    assert len(h) == 1000001
+    scene = rt.Scene(h)
+    info = scene.info
+    assert info["n_nodes"] == 1000000 and info["lds_resident"] == 0 and info["bvh_depth"] <= 27
+    cam = rt.Camera.build([0, 0, 0], [130, 40, 30], 1.0, 0.1, 1920, 1080)
+    rng = np.random.default_rng(1)
+    px = rng.choice(1920 * 1080, 384, replace=False)
+    o = np.concatenate([scene.generate_primary(cam, 0, int(p), int(p) + 1)[0] for p in px])
+    d = np.concatenate([scene.generate_primary(cam, 0, int(p), int(p) + 1)[1] for p in px])
+    # add secondary-like rays: from points just above the field in random upward directions
+    o2 = (rng.uniform(-200, 200, (128, 3)) * [1, 0, 1] + [0, 0.45, 0]).astype(np.float32)
+    o2[:, 1] = (np.sqrt(1000.2 ** 2 - o2[:, 0].astype(np.float64) ** 2 - o2[:, 2].astype(np.float64) ** 2) - 1000.0 + 0.25).astype(np.float32)
+    d2 = rng.normal(size=(128, 3)); d2[:, 1] = np.abs(d2[:, 1]) * 0.05
+    d2 = (d2 / np.linalg.norm(d2, axis=1, keepdims=True)).astype(np.float32)
+    o, d = np.concatenate([o, o2]), np.concatenate([d, d2])
+    ids, t, nrm = scene.trace_primary(o, d)
+    want_ids, want_t, want_n, _ = ob.Scene(h).trace(o, d, ob.TRAVERSE_GATED_BRUTE)
+    _check_hits(ids, t, nrm, want_ids, want_t, want_n)
+    assert (want_ids > 0).sum() > 150  # small spheres, not only the ground
+    # full-size render: finite, reproducible, sample ranges add up, schedules agree
+    from raytracer_amd import _abi
+    a, _ = scene.render(cam, 2, depth=50, seed=0, want_rgb8=False)
+    b, _ = scene.render(cam, 2, depth=50, seed=0, want_rgb8=False, flags=_abi.RT_RENDER_KERNEL_LOCKSTEP)
+    assert np.isfinite(a).all() and np.array_equal(a, b)
+    lo, _ = scene.render(cam, 1, depth=50, seed=0, sample_begin=0, want_rgb8=False)
+    hi, _ = scene.render(cam, 1, depth=50, seed=0, sample_begin=1, want_rgb8=False)
+    assert np.allclose(lo + hi, a, rtol=2e-6, atol=1e-6)
+
+
+def test_4k_frame_properties(scene1, rt):
+    # the 8-GPU configuration's frame size (3840x2160) at a token sample count
+    cam = rt.default_camera(3840, 2160)
+    s, q = scene1.render(cam, 1, depth=50, seed=0)
+    assert s.shape == (2160, 3840, 3) and np.isfinite(s).all() and 0.4 < s.mean() < 0.9
+    # same field of view as the 960x540 frame (the resolution only sets the pixel grid, src/camera.rs:59-78):
+    # 4x4 blocks of the 4K frame at 1 spp estimate the pixels of the small frame at 16 spp
+    small, _ = scene1.render(rt.default_camera(960, 540), 16, depth=50, seed=1)
+    blocks = s.reshape(540, 4, 960, 4, 3).sum(axis=(1, 3))
+    assert abs(blocks.mean() - small.mean()) < 0.01 * small.mean()
+    coarse_a = blocks.reshape(54, 10, 96, 10, 3).mean(axis=(1, 3))
+    coarse_b = small.reshape(54, 10, 96, 10, 3).mean(axis=(1, 3))
+    assert np.corrcoef(coarse_a.ravel(), coarse_b.ravel())[0, 1] > 0.99
+
+
 def test_argument_errors(scene1, rt):
     cam = rt.default_camera(16, 16)
     with pytest.raises(rt.RtError) as e:
