@@ -100,6 +100,10 @@ typedef struct rt_render_opts {
     uint32_t depth;        /* scatter_depth of src/lib.rs:88 (the reference passes 10, src/lib.rs:172) */
     uint32_t flags;        /* RT_RENDER_* */
     uint64_t seed;         /* Philox4x32-10 key; counter = (pixel, sample, bounce, attempt) */
+    uint32_t samples_per_item; /* a pixel's samples are traced in chunks of this many by whichever lane is free; a chunk
+                                  is summed in sample order, the chunks are added in chunk order.  0 = chosen from
+                                  the frame size (rt_render_chunk reports it) */
+    uint32_t reserved;
 } rt_render_opts;
 enum {
     RT_RENDER_ACCUMULATE = 1,          /* add to the buffer instead of overwriting it */
@@ -157,6 +161,9 @@ int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_render_opts
  * {inner-node turns*64, lanes in them, leaf turns*64, lanes, shade turns*64, lanes shading or
  * regenerating, lanes regenerating, descent-loop turns*64}.  Synchronises the device. */
 int rt_debug_render_stats(rt_scene* scene, uint64_t out[8]);
+
+/* Chunk size rt_render_device uses for this frame and sample range (the summation order of the image). */
+int rt_render_chunk(const rt_camera* cam, const rt_render_opts* opts, uint32_t* samples_per_item);
 
 /* (1/spp) * sum, then color_to_ppm (src/lib.rs:148-149, :186-192): device
  * buffers, n_pixels*3 channels. */

@@ -83,6 +83,8 @@ class rt_render_opts(C.Structure):
         ("depth", C.c_uint32),
         ("flags", C.c_uint32),
         ("seed", C.c_uint64),
+        ("samples_per_item", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 
@@ -104,6 +106,7 @@ PROTOTYPES = {
     "rt_scene_get_info": (_i, [_vp, C.POINTER(rt_scene_info)]),
     "rt_render_device": (_i, [_vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts), _vp, _vp]),
     "rt_debug_render_stats": (_i, [_vp, _vp]),
+    "rt_render_chunk": (_i, [C.POINTER(rt_camera), C.POINTER(rt_render_opts), C.POINTER(_u32)]),
     "rt_finalize_device": (_i, [_vp, _vp, _sz, _u32, _vp, _vp]),
     "rt_render": (_i, [_vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts), _vp, _vp]),
     "rt_trace_primary": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp]),

@@ -159,23 +159,34 @@ class Scene:
         return {k: getattr(i, k) for k, _ in i._fields_}
 
     @staticmethod
-    def opts(sample_begin, sample_end, depth, seed, flags=0):
+    def opts(sample_begin, sample_end, depth, seed, flags=0, samples_per_item=0):
         o = _abi.rt_render_opts()
         o.sample_begin, o.sample_end, o.depth, o.flags, o.seed = int(sample_begin), int(sample_end), int(depth), int(flags), int(seed)
+        o.samples_per_item = int(samples_per_item)
         return o
 
-    def render(self, cam, spp, depth=REFERENCE_DEPTH, seed=0, sample_begin=0, want_sum=True, want_rgb8=True, flags=0):
+    @staticmethod
+    def render_chunk(cam, spp, sample_begin=0, samples_per_item=0):
+        """Samples per work item (the image's summation order) for this frame and sample count."""
+        o = Scene.opts(sample_begin, sample_begin + spp, 1, 0, 0, samples_per_item)
+        out = C.c_uint32(0)
+        check(lib.rt_render_chunk(C.byref(cam.c), C.byref(o), C.byref(out)))
+        return out.value
+
+    def render(self, cam, spp, depth=REFERENCE_DEPTH, seed=0, sample_begin=0, want_sum=True, want_rgb8=True, flags=0,
+               samples_per_item=0):
         """Host-buffer render: returns (sum_rgb float32 (H,W,3) or None, rgb8 (H,W,3) or None)."""
         H, W = cam.vert_res, cam.horiz_res
         s = np.zeros((H, W, 3), dtype=np.float32) if want_sum else None
         q = np.zeros((H, W, 3), dtype=np.uint8) if want_rgb8 else None
-        o = self.opts(sample_begin, sample_begin + spp, depth, seed, flags)
+        o = self.opts(sample_begin, sample_begin + spp, depth, seed, flags, samples_per_item)
         check(lib.rt_render(self.handle, C.byref(cam.c), C.byref(o), ptr(s), ptr(q)))
         return s, q
 
-    def render_device(self, cam, d_sum_ptr, sample_begin, sample_end, depth, seed, stream=None, accumulate=False, flags=0):
+    def render_device(self, cam, d_sum_ptr, sample_begin, sample_end, depth, seed, stream=None, accumulate=False, flags=0,
+                      samples_per_item=0):
         """Asynchronous render into device memory (d_sum_ptr: integer address of W*H*3 floats)."""
-        o = self.opts(sample_begin, sample_end, depth, seed, flags | (_abi.RT_RENDER_ACCUMULATE if accumulate else 0))
+        o = self.opts(sample_begin, sample_end, depth, seed, flags | (_abi.RT_RENDER_ACCUMULATE if accumulate else 0), samples_per_item)
         check(lib.rt_render_device(self.handle, C.byref(cam.c), C.byref(o), C.c_void_p(d_sum_ptr), C.c_void_p(stream or 0)))
 
     def finalize_device(self, d_sum_ptr, n_pixels, spp_total, d_rgb8_ptr, stream=None):

@@ -73,6 +73,7 @@ struct RenderParams {
     uint32_t key0, key1;
     uint32_t n_pixels, tiles_x, tiles_y;
     uint32_t trav_threshold, inner_threshold;  // schedule of render_kernel_ws
+    uint32_t n_chunks, chunk_spp;              // a work item = one 8x8 tile x one chunk of chunk_spp samples
 };
 
 // ---------------------------------------------------------------- Philox
@@ -487,16 +488,75 @@ __device__ __forceinline__ bool advance(const SceneDev& S, const RenderParams& P
     return true;
 }
 
+// Sum of one finished item: straight into the image when a pixel is a single item, else into the
+// item's own slot of the partial-sum buffer (combine_kernel adds the slots in chunk order).
+__device__ __forceinline__ void flush_item(const RenderParams& P, float* sum_rgb, float* partials, uint32_t pixel,
+                                           uint32_t chunk, float ar, float ag, float ab) {
+    if (P.n_chunks == 1) {
+        float* out = sum_rgb + 3 * size_t(pixel);
+        if (P.flags & RT_RENDER_ACCUMULATE) { ar += out[0]; ag += out[1]; ab += out[2]; }
+        out[0] = ar; out[1] = ag; out[2] = ab;
+    } else {
+        float* out = partials + 3 * (size_t(chunk) * P.n_pixels + pixel);
+        out[0] = ar; out[1] = ag; out[2] = ab;
+    }
+}
+
+// Work hand-out.  A work item is one 8x8 pixel tile x one chunk of samples.  A wave draws an item from
+// the global counter with ONE atomic and deals its 64 pixels to its lanes as they ask, so the counter
+// sees one request per item instead of one per pixel (a single word serves only ~90 requests per
+// microsecond).  ws = this wave's two LDS words {item, next undealt pixel of its tile}; called by the
+// lanes that need work.  Chunks keep the items small enough to balance the end of the launch: with one
+// item per pixel and 100 samples each, a third of the launch was spent waiting for the last items.
+__device__ __forceinline__ void claim_pixels(bool& need, bool& done, uint32_t& pixel, uint32_t& chunk, volatile uint32_t* ws,
+                                             uint32_t* work_counter, const RenderParams& P, const CamDev& C) {
+    const uint32_t n_items = P.tiles_x * P.tiles_y * P.n_chunks;
+    const uint32_t lane = __lane_id();
+    unsigned long long m = __ballot(need);
+    while (m) {
+        uint32_t item = ws[0], next = ws[1];
+        if (next >= 64u) {
+            const int first = __ffsll((long long)m) - 1;
+            uint32_t w = 0;
+            if (int(lane) == first) w = atomicAdd(work_counter, 1u);
+            item = uint32_t(__shfl(int(w), first));
+            next = 0;
+        }
+        if (item >= n_items) {  // nothing left: remember it, so later calls cost no atomic
+            if (need) { done = true; need = false; }
+            ws[0] = 0xffffffffu;
+            ws[1] = 0;
+            break;
+        }
+        const uint32_t rank = uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
+        const uint32_t avail = 64u - next;
+        if (need && rank < avail) {
+            const uint32_t in_tile = next + rank;  // row-major inside the tile
+            const uint32_t tile = item / P.n_chunks;
+            const uint32_t x = (tile % P.tiles_x) * 8u + (in_tile & 7u);
+            const uint32_t y = (tile / P.tiles_x) * 8u + (in_tile >> 3);
+            if (x < C.W && y < C.H) { pixel = y * C.W + x; chunk = item % P.n_chunks; need = false; }  // outside the frame: ask again
+        }
+        const uint32_t asked = uint32_t(__popcll(m));
+        ws[0] = item;
+        ws[1] = next + (asked < avail ? asked : avail);
+        m = __ballot(need);
+    }
+}
+
 // ---------------------------------------------------------------- kernels
 // Persistent render kernel.  A lane owns one pixel at a time and walks its
 // samples in order, so a pixel's sum is formed in sample order by one lane: no
 // atomics on the image and bit-reproducible output.  A lane whose path ends
 // starts the pixel's next sample at once; a lane whose pixel is finished draws
 // the next pixel index from a global counter.
-__global__ __launch_bounds__(kBlock) void render_kernel(SceneDev S, CamDev C, RenderParams P, float* __restrict__ sum_rgb,
+__global__ __launch_bounds__(kBlock) void render_kernel(SceneDev S, CamDev C, RenderParams P, uint32_t stack_depth,
+                                                        float* __restrict__ sum_rgb, float* __restrict__ partials,
                                                         uint32_t* __restrict__ work_counter) {
     extern __shared__ int32_t stack_lds[];
     int32_t* stk = stack_lds + threadIdx.x;
+    volatile uint32_t* wave_state = reinterpret_cast<uint32_t*>(stack_lds + stack_depth * kBlock) + 2 * (threadIdx.x >> 6);
+    if ((threadIdx.x & 63) == 0) { wave_state[0] = 0; wave_state[1] = 64; }
 
     Path p;
     p.ox = p.oy = p.oz = 0.0;
@@ -504,36 +564,26 @@ __global__ __launch_bounds__(kBlock) void render_kernel(SceneDev S, CamDev C, Re
     p.tr = p.tg = p.tb = 0.0f;
     p.pixel = 0; p.sample = 0; p.bounce = 0;
     bool have_pixel = false, alive = false, done = false;
-    uint32_t next_sample = 0;
+    uint32_t next_sample = 0, item_end = 0, chunk = 0;
     float ar = 0.0f, ag = 0.0f, ab = 0.0f;
-    const uint32_t n_work = P.tiles_x * P.tiles_y * 64u;
 
     for (;;) {
         if (!alive && !done) {
-            if (have_pixel && next_sample >= P.sample_end) {  // pixel finished: write its sum
-                float* out = sum_rgb + 3 * size_t(p.pixel);
-                if (P.flags & RT_RENDER_ACCUMULATE) { ar += out[0]; ag += out[1]; ab += out[2]; }
-                out[0] = ar; out[1] = ag; out[2] = ab;
+            if (have_pixel && next_sample >= item_end) {  // item finished: write its sum
+                flush_item(P, sum_rgb, partials, p.pixel, chunk, ar, ag, ab);
                 have_pixel = false;
             }
             if (!have_pixel) {
-                const uint32_t w = atomicAdd(work_counter, 1u);
-                if (w >= n_work) {
-                    done = true;
-                } else {
-                    // work index -> pixel: 8x8 tiles, row-major inside the tile
-                    const uint32_t tile = w >> 6, in_tile = w & 63u;
-                    const uint32_t x = (tile % P.tiles_x) * 8u + (in_tile & 7u);
-                    const uint32_t y = (tile / P.tiles_x) * 8u + (in_tile >> 3);
-                    if (x < C.W && y < C.H) {
-                        have_pixel = true;
-                        p.pixel = y * C.W + x;
-                        next_sample = P.sample_begin;
-                        ar = ag = ab = 0.0f;
-                    }
+                bool need = true;
+                claim_pixels(need, done, p.pixel, chunk, wave_state, work_counter, P, C);
+                if (!done) {
+                    have_pixel = true;
+                    next_sample = P.sample_begin + chunk * P.chunk_spp;
+                    item_end = min(next_sample + P.chunk_spp, P.sample_end);
+                    ar = ag = ab = 0.0f;
                 }
             }
-            if (have_pixel && next_sample < P.sample_end) {
+            if (have_pixel && next_sample < item_end) {
                 if (P.depth == 0) {  // `for _ in 1..=0` never runs: the colour is the initial throughput
                     ar += 1.0f; ag += 1.0f; ab += 1.0f;
                 } else {
@@ -695,15 +745,18 @@ __device__ __forceinline__ void leaf_step(const SceneDev& S, const double4* lds_
 template <bool LDS16, int BLOCK, bool STATS>
 __global__ __launch_bounds__(BLOCK) void render_kernel_ws(SceneDev S, CamDev C, RenderParams P,
                                                           const Node16* __restrict__ nodes16, uint32_t stack_depth,
-                                                          float* __restrict__ sum_rgb, uint32_t* __restrict__ work_counter) {
+                                                          float* __restrict__ sum_rgb, float* __restrict__ partials,
+                                                          uint32_t* __restrict__ work_counter) {
     uint32_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     extern __shared__ uint4 lds_raw[];
     // LDS layout (16-byte units): [q0: n_nodes][q1: n_nodes][spheres: 2*n_spheres][stack: stack_depth*BLOCK/4]
     uint4* lds_q0 = lds_raw;
     uint4* lds_q1 = lds_raw + (LDS16 ? S.n_nodes : 0);
     double4* lds_sph = reinterpret_cast<double4*>(lds_raw + (LDS16 ? 2 * S.n_nodes : 0));
-    int32_t* stk = reinterpret_cast<int32_t*>(lds_raw + (LDS16 ? 2 * S.n_nodes + 2 * S.n_spheres : 0)) + threadIdx.x;
-    (void)stack_depth;
+    int32_t* stk0 = reinterpret_cast<int32_t*>(lds_raw + (LDS16 ? 2 * S.n_nodes + 2 * S.n_spheres : 0));
+    int32_t* stk = stk0 + threadIdx.x;
+    volatile uint32_t* wave_state = reinterpret_cast<uint32_t*>(stk0 + stack_depth * BLOCK) + 2 * (threadIdx.x >> 6);
+    if ((threadIdx.x & 63) == 0) { wave_state[0] = 0; wave_state[1] = 64; }
     if (LDS16) {
         const uint4* src = reinterpret_cast<const uint4*>(nodes16);
         for (int32_t i = threadIdx.x; i < S.n_nodes; i += BLOCK) { lds_q0[i] = src[2 * i]; lds_q1[i] = src[2 * i + 1]; }
@@ -726,9 +779,8 @@ __global__ __launch_bounds__(BLOCK) void render_kernel_ws(SceneDev S, CamDev C, 
 #pragma unroll
     for (int a = 0; a < 3; ++a) { T.inv[a] = 0.0f; T.A[a] = 0.0f; T.B[a] = 0.0f; }
     bool have_pixel = false, alive = false, done = false;
-    uint32_t next_sample = 0;
+    uint32_t next_sample = 0, item_end = 0, chunk = 0;
     float ar = 0.0f, ag = 0.0f, ab = 0.0f;
-    const uint32_t n_work = P.tiles_x * P.tiles_y * 64u;
     const int trav_threshold = int(P.trav_threshold), inner_threshold = int(P.inner_threshold);
 
     for (;;) {
@@ -748,29 +800,21 @@ __global__ __launch_bounds__(BLOCK) void render_kernel_ws(SceneDev S, CamDev C, 
                 }
             }
             if (!alive) {
-                if (have_pixel && next_sample >= P.sample_end) {
-                    float* out = sum_rgb + 3 * size_t(p.pixel);
-                    if (P.flags & RT_RENDER_ACCUMULATE) { ar += out[0]; ag += out[1]; ab += out[2]; }
-                    out[0] = ar; out[1] = ag; out[2] = ab;
+                if (have_pixel && next_sample >= item_end) {
+                    flush_item(P, sum_rgb, partials, p.pixel, chunk, ar, ag, ab);
                     have_pixel = false;
                 }
                 if (!have_pixel) {
-                    const uint32_t w = atomicAdd(work_counter, 1u);
-                    if (w >= n_work) {
-                        done = true;
-                    } else {
-                        const uint32_t tile = w >> 6, in_tile = w & 63u;
-                        const uint32_t x = (tile % P.tiles_x) * 8u + (in_tile & 7u);
-                        const uint32_t y = (tile / P.tiles_x) * 8u + (in_tile >> 3);
-                        if (x < C.W && y < C.H) {
-                            have_pixel = true;
-                            p.pixel = y * C.W + x;
-                            next_sample = P.sample_begin;
-                            ar = ag = ab = 0.0f;
-                        }
+                    bool need = true;
+                    claim_pixels(need, done, p.pixel, chunk, wave_state, work_counter, P, C);
+                    if (!done) {
+                        have_pixel = true;
+                        next_sample = P.sample_begin + chunk * P.chunk_spp;
+                        item_end = min(next_sample + P.chunk_spp, P.sample_end);
+                        ar = ag = ab = 0.0f;
                     }
                 }
-                if (have_pixel && next_sample < P.sample_end) {
+                if (have_pixel && next_sample < item_end) {
                     if (P.depth == 0) {
                         ar += 1.0f; ag += 1.0f; ab += 1.0f;
                     } else {
@@ -905,6 +949,16 @@ __global__ __launch_bounds__(kBlock) void trace_primary_kernel(SceneDev S, const
     normal[3 * size_t(g)] = nx; normal[3 * size_t(g) + 1] = ny; normal[3 * size_t(g) + 2] = nz;
 }
 
+// image = (old image when accumulating) + partial sums in chunk order
+__global__ __launch_bounds__(kBlock) void combine_kernel(const float* __restrict__ partials, uint32_t n_chunks, size_t n_channels,
+                                                         uint32_t accumulate, float* __restrict__ sum_rgb) {
+    const size_t g = size_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (g >= n_channels) return;
+    float acc = accumulate ? sum_rgb[g] : 0.0f;
+    for (uint32_t c = 0; c < n_chunks; ++c) acc += partials[size_t(c) * n_channels + g];
+    sum_rgb[g] = acc;
+}
+
 // (1/spp)*sum then color_to_ppm (src/lib.rs:148-149, :186-192), in f64 like the reference.
 __global__ __launch_bounds__(kBlock) void finalize_kernel(const float* __restrict__ sum_rgb, size_t n_channels,
                                                           double inv_spp, uint8_t* __restrict__ rgb8) {
@@ -930,6 +984,8 @@ struct rt_scene {
     SceneDev dev{};
     std::vector<void*> allocations;
     uint32_t* d_work_counter = nullptr;
+    float* d_partials = nullptr;        // partial-sum slots of chunked renders, grown on demand
+    size_t partials_bytes = 0;
     const Node16* d_nodes16 = nullptr;  // f16 copy of the nodes for the LDS-resident kernel, or null
     size_t lds16_scene_bytes = 0;
     uint32_t stack_depth = 0;
@@ -1006,7 +1062,8 @@ float descent_eps(const rt_scene* sc, double origin_abs) {
     return float(extent * (1.0 / 2097152.0));  // 2^-21 of the largest distance between a box plane and an origin
 }
 
-size_t stack_bytes(const rt_scene* sc) { return size_t(std::max<uint32_t>(sc->stack_depth, 1u)) * kBlock * sizeof(int32_t); }
+// LDS of the 256-thread kernels: the traversal stack plus two words of pixel hand-out state per wave
+size_t stack_bytes(const rt_scene* sc) { return size_t(std::max<uint32_t>(sc->stack_depth, 1u)) * kBlock * sizeof(int32_t) + 64; }
 
 int check_render_args(const rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, const char* who) {
     if (!scene || !cam || !opts) return fail(RT_ERR_INVALID_ARGUMENT, "%s: null argument", who);
@@ -1029,6 +1086,17 @@ RenderParams make_params(const rt_camera& cam, const rt_render_opts& o) {
     P.n_pixels = cam.horiz_res * cam.vert_res;
     P.tiles_x = (cam.horiz_res + 7) / 8;
     P.tiles_y = (cam.vert_res + 7) / 8;
+    // enough items to keep every lane of the chip busy to the end: about 32 items per resident lane
+    const uint32_t spp = o.sample_end - o.sample_begin;
+    if (o.samples_per_item) {
+        P.chunk_spp = std::min<uint32_t>(o.samples_per_item, spp);
+    } else {
+        const uint64_t want_items = 8u << 20;
+        uint32_t chunks = uint32_t(std::min<uint64_t>(std::max<uint64_t>(1, want_items / std::max<uint32_t>(P.n_pixels, 1)), 64));
+        chunks = std::max<uint32_t>(1, std::min<uint32_t>(chunks, spp));
+        P.chunk_spp = (spp + chunks - 1) / chunks;
+    }
+    P.n_chunks = (spp + P.chunk_spp - 1) / P.chunk_spp;
     P.trav_threshold = kTravThreshold;
     P.inner_threshold = kInnerThreshold;
     if (const char* e = std::getenv("RT_TRAV_THRESHOLD")) P.trav_threshold = uint32_t(std::atoi(e));    // tuning aid
@@ -1055,6 +1123,7 @@ int rt_device_count(void) {
 void rt_scene_destroy(rt_scene* scene) {
     if (!scene) return;
     (void)hipSetDevice(scene->device);
+    if (scene->d_partials) (void)hipFree(scene->d_partials);
     for (void* p : scene->allocations) (void)hipFree(p);
     delete scene;
 }
@@ -1242,7 +1311,16 @@ int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_render_opts
     S.eps = descent_eps(scene, camera_abs(*cam));
     const CamDev C = make_cam(*cam);
     const RenderParams P = make_params(*cam, *opts);
-    const uint64_t n_work = uint64_t(P.tiles_x) * P.tiles_y * 64u;
+    const uint64_t n_work = uint64_t(P.tiles_x) * P.tiles_y * 64u * P.n_chunks;
+    if (P.n_chunks > 1) {
+        const size_t need = size_t(P.n_chunks) * P.n_pixels * 3 * sizeof(float);
+        if (need > scene->partials_bytes) {  // grown on demand, kept for later renders of this scene
+            RT_HIP(hipStreamSynchronize(st));
+            if (scene->d_partials) { (void)hipFree(scene->d_partials); scene->d_partials = nullptr; scene->partials_bytes = 0; }
+            RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_partials), need));
+            scene->partials_bytes = need;
+        }
+    }
     RT_HIP(hipMemsetAsync(scene->d_work_counter, 0, 256, st));
     auto grid_for = [&](int per_cu, int block) {
         uint64_t blocks = uint64_t(scene->n_cu) * uint64_t(per_cu < 1 ? 1 : per_cu);
@@ -1252,23 +1330,37 @@ int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_render_opts
     if (opts->flags & RT_RENDER_KERNEL_LOCKSTEP) {
         const size_t lds = stack_bytes(scene);
         RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel, kBlock, lds));
-        hipLaunchKernelGGL(render_kernel, grid_for(per_cu, kBlock), dim3(kBlock), lds, st, S, C, P, d_sum_rgb, scene->d_work_counter);
+        hipLaunchKernelGGL(render_kernel, grid_for(per_cu, kBlock), dim3(kBlock), lds, st, S, C, P,
+                           std::max<uint32_t>(scene->stack_depth, 1u), d_sum_rgb, scene->d_partials, scene->d_work_counter);
     } else if (scene->d_nodes16 && !(opts->flags & RT_RENDER_KERNEL_NO_LDS_SCENE)) {
         constexpr int B = 512;
-        const size_t lds = scene->lds16_scene_bytes + size_t(std::max<uint32_t>(scene->stack_depth, 1u)) * B * sizeof(int32_t);
+        const size_t lds = scene->lds16_scene_bytes + size_t(std::max<uint32_t>(scene->stack_depth, 1u)) * B * sizeof(int32_t) + 64;
         auto k = (opts->flags & RT_RENDER_STATS) ? render_kernel_ws<true, B, true> : render_kernel_ws<true, B, false>;
         RT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, B, lds));
-        hipLaunchKernelGGL(k, grid_for(per_cu, B), dim3(B), lds, st, S, C, P, scene->d_nodes16, scene->stack_depth, d_sum_rgb,
-                           scene->d_work_counter);
+        hipLaunchKernelGGL(k, grid_for(per_cu, B), dim3(B), lds, st, S, C, P, scene->d_nodes16,
+                           std::max<uint32_t>(scene->stack_depth, 1u), d_sum_rgb, scene->d_partials, scene->d_work_counter);
     } else {
         const size_t lds = stack_bytes(scene);
         auto k = (opts->flags & RT_RENDER_STATS) ? render_kernel_ws<false, kBlock, true> : render_kernel_ws<false, kBlock, false>;
         RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, kBlock, lds));
         hipLaunchKernelGGL(k, grid_for(per_cu, kBlock), dim3(kBlock), lds, st, S, C, P, static_cast<const Node16*>(nullptr),
-                           scene->stack_depth, d_sum_rgb, scene->d_work_counter);
+                           std::max<uint32_t>(scene->stack_depth, 1u), d_sum_rgb, scene->d_partials, scene->d_work_counter);
     }
     RT_HIP(hipGetLastError());
+    if (P.n_chunks > 1) {
+        const size_t n = size_t(P.n_pixels) * 3;
+        hipLaunchKernelGGL(combine_kernel, dim3(uint32_t((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, scene->d_partials, P.n_chunks, n,
+                           uint32_t(opts->flags & RT_RENDER_ACCUMULATE), d_sum_rgb);
+        RT_HIP(hipGetLastError());
+    }
+    return RT_OK;
+}
+
+int rt_render_chunk(const rt_camera* cam, const rt_render_opts* opts, uint32_t* samples_per_item) {
+    if (!cam || !opts || !samples_per_item) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_chunk: null argument");
+    if (opts->sample_end <= opts->sample_begin) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_chunk: empty sample range");
+    *samples_per_item = make_params(*cam, *opts).chunk_spp;
     return RT_OK;
 }
 

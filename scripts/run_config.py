@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--stats", action="store_true")
     ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -33,7 +35,7 @@ def main():
     earth = np.load(os.path.join(ROOT, "tests", "golden", "earthmap_rgb8.npz"))["rgb8"]
     t0 = time.time()
     if a.config in ("c2", "c2d10"):
-        h, tex, cam, spp, depth = rt.gen_scene(1), [], rt.default_camera(1920, 1080), 100, (50 if a.config == "c2" else 10)
+        h, tex, cam, spp, depth = rt.gen_scene(1), [], rt.default_camera(a.width, a.height), 100, (50 if a.config == "c2" else 10)
     elif a.config == "c4":
         h, tex, spp, depth = rt.gen_scene_shells(8), [earth], 100, 50
         cam = rt.Camera.build([0, 0, 1], [0, 1.5, -5], 1.0, 0.1, 1920, 1080)

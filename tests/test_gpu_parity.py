@@ -207,10 +207,22 @@ def test_all_render_schedules_give_the_same_image(scene1, rt):
     px = np.repeat(np.arange(200 * 120, dtype=np.uint32), 6)
     sm = np.tile(np.arange(6, dtype=np.uint32), 200 * 120)
     cols = scene1.trace_paths(cam, px, sm, depth=50, seed=8).reshape(200 * 120, 6, 3)
-    acc = np.zeros((200 * 120, 3), dtype=np.float32)
-    for k in range(6):
-        acc += cols[:, k, :]
-    assert np.array_equal(acc.reshape(120, 200, 3), a)
+
+    def ordered_sum(chunk):  # chunks of samples summed in sample order, then added in chunk order
+        total = np.zeros((200 * 120, 3), dtype=np.float32)
+        for c0 in range(0, 6, chunk):
+            part = np.zeros((200 * 120, 3), dtype=np.float32)
+            for k in range(c0, min(c0 + chunk, 6)):
+                part += cols[:, k, :]
+            total += part
+        return total.reshape(120, 200, 3)
+
+    assert np.array_equal(ordered_sum(scene1.render_chunk(cam, 6)), a)
+    for chunk in (1, 4, 6):
+        d, _ = scene1.render(cam, 6, depth=50, seed=8, samples_per_item=chunk)
+        assert scene1.render_chunk(cam, 6, samples_per_item=chunk) == chunk
+        assert np.array_equal(ordered_sum(chunk), d)
+    assert np.allclose(a, ordered_sum(6), rtol=2e-6, atol=1e-6)  # the chunking only reorders an f32 sum
 
 
 def test_finalize_matches_color_to_ppm(scene1, ob, rt):
