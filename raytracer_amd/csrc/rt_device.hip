@@ -95,6 +95,9 @@ __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
     return make_uint4(c0, c1, c2, c3);
 }
 __device__ __forceinline__ float u01(uint32_t x) { return float(x >> 8) * (1.0f / 16777216.0f); }
+// v_rcp_f32 / v_sqrt_f32: one instruction, about 1 ulp (the IEEE-exact forms cost ~10 instructions each)
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
 // sin/cos of 2*pi*rev (v_sin_f32 / v_cos_f32 take revolutions)
 __device__ __forceinline__ void sincos_rev(float rev, float* s, float* c) {
@@ -105,7 +108,7 @@ __device__ __forceinline__ void sincos_rev(float rev, float* s, float* c) {
 __device__ __forceinline__ void unit_sphere(float u0, float u1, float* x, float* y, float* z) {
 #pragma clang fp contract(off)
     float zz = 1.0f - 2.0f * u0;
-    float r = sqrtf(fmaxf(0.0f, 1.0f - zz * zz));
+    float r = fast_sqrt(fmaxf(0.0f, 1.0f - zz * zz));
     float s, c;
     sincos_rev(u1, &s, &c);
     *x = r * c;
@@ -204,7 +207,7 @@ __device__ __forceinline__ Best closest_hit(const SceneDev& S, double ox, double
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         float d = df[a];
-        float i = (fabsf(d) >= 1.0e-18f) ? __frcp_rn(d) : copysignf(1.0e18f, d);
+        float i = (fabsf(d) >= 1.0e-18f) ? fast_rcp(d) : copysignf(1.0e18f, d);
         inv[a] = i;
         A[a] = -(of[a] + S.eps) * i;
         B[a] = -(of[a] - S.eps) * i;
@@ -299,13 +302,12 @@ __device__ __forceinline__ void unit_f64(float x, float y, float z, double* X, d
 // src/camera.rs:49-78 + src/ray.rs:9-11 with the two rejection loops replaced
 // by direct draws of the same distributions (quarter disc, unit square).
 // r = Philox block (pixel, sample, 0, 0).
-__device__ __forceinline__ void camera_ray_from(const CamDev& C, uint32_t pixel, const uint4 r, float o[3], float d[3]) {
+__device__ __forceinline__ void camera_ray_from(const CamDev& C, uint32_t i, uint32_t j, const uint4 r, float o[3], float d[3]) {
 #pragma clang fp contract(off)
-    const float rad = sqrtf(u01(r.x));
+    const float rad = fast_sqrt(u01(r.x));
     float s, c;
     sincos_rev(0.25f * u01(r.y), &s, &c);
     const float la = C.aperture * (rad * c), lb = C.aperture * (rad * s);
-    const uint32_t i = pixel % C.W, j = pixel / C.W;
     const float gh = (-0.5f + float(i) * C.inv_w) * C.span + u01(r.z) * C.inv_w;
     const float gv = (0.5f - float(j) * C.inv_h) * C.span + u01(r.w) * C.inv_h;
 #pragma unroll
@@ -318,12 +320,13 @@ __device__ __forceinline__ void camera_ray_from(const CamDev& C, uint32_t pixel,
 
 __device__ __forceinline__ void camera_ray(const CamDev& C, const RenderParams& P, uint32_t pixel, uint32_t sample,
                                            float o[3], float d[3]) {
-    camera_ray_from(C, pixel, philox4x32_10(pixel, sample, 0u, 0u, P.key0, P.key1), o, d);
+    camera_ray_from(C, pixel % C.W, pixel / C.W, philox4x32_10(pixel, sample, 0u, 0u, P.key0, P.key1), o, d);
 }
 
-__device__ __forceinline__ void start_path_from(const CamDev& C, uint32_t pixel, uint32_t sample, const uint4 r, Path& p) {
+__device__ __forceinline__ void start_path_from(const CamDev& C, uint32_t pixel, uint32_t px, uint32_t py, uint32_t sample,
+                                                const uint4 r, Path& p) {
     float o[3], d[3];
-    camera_ray_from(C, pixel, r, o, d);
+    camera_ray_from(C, px, py, r, o, d);
     p.ox = double(o[0]); p.oy = double(o[1]); p.oz = double(o[2]);
     unit_f64(d[0], d[1], d[2], &p.dx, &p.dy, &p.dz);
     p.tr = p.tg = p.tb = 1.0f;
@@ -332,7 +335,7 @@ __device__ __forceinline__ void start_path_from(const CamDev& C, uint32_t pixel,
 
 __device__ __forceinline__ void start_path(const CamDev& C, const RenderParams& P, uint32_t pixel, uint32_t sample,
                                            Path& p) {
-    start_path_from(C, pixel, sample, philox4x32_10(pixel, sample, 0u, 0u, P.key0, P.key1), p);
+    start_path_from(C, pixel, pixel % C.W, pixel / C.W, sample, philox4x32_10(pixel, sample, 0u, 0u, P.key0, P.key1), p);
 }
 
 // src/materials.rs:59-76 + :159-171 + src/lib.rs:194-200
@@ -350,9 +353,9 @@ __device__ __forceinline__ void texture_albedo(const SceneDev& S, int32_t texmat
     uint32_t col = (colf > 0.0f) ? (colf >= 4294967040.0f ? 4294967295u : uint32_t(colf)) : 0u;
     uint32_t row = (rowf > 0.0f) ? (rowf >= 4294967040.0f ? 4294967295u : uint32_t(rowf)) : 0u;
     const uchar4 px = img.px[size_t(row % img.h) * img.w + (col % img.w)];
-    *r = float(px.x) / 255.0f;
-    *g = float(px.y) / 255.0f;
-    *b = float(px.z) / 255.0f;
+    *r = float(px.x) * (1.0f / 255.0f);
+    *g = float(px.y) * (1.0f / 255.0f);
+    *b = float(px.z) * (1.0f / 255.0f);
 }
 
 // What the scatter step needs to know about the surface that was hit.
@@ -388,7 +391,7 @@ __device__ __forceinline__ bool hit_part(const SceneDev& S, const RenderParams& 
     if (k < S.n_spheres) {
         const double4 s = S.sph[k];
         const float rx = float(sf.hx - s.x), ry = float(sf.hy - s.y), rz = float(sf.hz - s.z);
-        const float inv_r = 1.0f / float(s.w);
+        const float inv_r = fast_rcp(float(s.w));
         sf.nx = rx * inv_r; sf.ny = ry * inv_r; sf.nz = rz * inv_r;  // src/geometry.rs:123-125
         lx = rx; ly = ry; lz = rz;
     } else {
@@ -431,12 +434,12 @@ __device__ __forceinline__ bool scatter_part(const RenderParams& P, Path& p, con
         const float inc_cos = ddn;
         const float px = dxf - inc_cos * nx, py = dyf - inc_cos * ny, pz = dzf - inc_cos * nz;
         const bool entering = __float_as_uint(inc_cos) >> 31;  // signum < 0 (also for -0.0)
-        const float ratio = entering ? 1.0f / sf.w : sf.w;
+        const float ratio = entering ? fast_rcp(sf.w) : sf.w;
         const float qx = ratio * px, qy = ratio * py, qz = ratio * pz;
         const float sin2 = qx * qx + qy * qy + qz * qz;
         bool reflect = sin2 > 1.0f;
         if (!reflect) {  // the Schlick draw counts only when sin2 <= 1 (`||` short-circuits)
-            float r0f = (1.0f - ratio) / (1.0f + ratio);
+            float r0f = (1.0f - ratio) * fast_rcp(1.0f + ratio);
             r0f = r0f * r0f;
             const float x = 1.0f - fabsf(inc_cos);
             const float reflectance = r0f + (1.0f - r0f) * (x * x * x * x * x);
@@ -445,7 +448,7 @@ __device__ __forceinline__ bool scatter_part(const RenderParams& P, Path& p, con
         if (reflect) {
             sx = px - inc_cos * nx; sy = py - inc_cos * ny; sz = pz - inc_cos * nz;
         } else {
-            const float sc_cos = (entering ? -1.0f : 1.0f) * sqrtf(1.0f - sin2);
+            const float sc_cos = (entering ? -1.0f : 1.0f) * fast_sqrt(1.0f - sin2);
             sx = qx + sc_cos * nx; sy = qy + sc_cos * ny; sz = qz + sc_cos * nz;
         }
     } else {
@@ -508,7 +511,7 @@ __device__ __forceinline__ void flush_item(const RenderParams& P, float* sum_rgb
 // microsecond).  ws = this wave's two LDS words {item, next undealt pixel of its tile}; called by the
 // lanes that need work.  Chunks keep the items small enough to balance the end of the launch: with one
 // item per pixel and 100 samples each, a third of the launch was spent waiting for the last items.
-__device__ __forceinline__ void claim_pixels(bool& need, bool& done, uint32_t& pixel, uint32_t& chunk, volatile uint32_t* ws,
+__device__ __forceinline__ void claim_pixels(bool& need, bool& done, uint32_t& pixel, uint32_t& xy, uint32_t& chunk, volatile uint32_t* ws,
                                              uint32_t* work_counter, const RenderParams& P, const CamDev& C) {
     const uint32_t n_items = P.tiles_x * P.tiles_y * P.n_chunks;
     const uint32_t lane = __lane_id();
@@ -535,7 +538,7 @@ __device__ __forceinline__ void claim_pixels(bool& need, bool& done, uint32_t& p
             const uint32_t tile = item / P.n_chunks;
             const uint32_t x = (tile % P.tiles_x) * 8u + (in_tile & 7u);
             const uint32_t y = (tile / P.tiles_x) * 8u + (in_tile >> 3);
-            if (x < C.W && y < C.H) { pixel = y * C.W + x; chunk = item % P.n_chunks; need = false; }  // outside the frame: ask again
+            if (x < C.W && y < C.H) { pixel = y * C.W + x; xy = x | (y << 16); chunk = item % P.n_chunks; need = false; }  // outside the frame: ask again
         }
         const uint32_t asked = uint32_t(__popcll(m));
         ws[0] = item;
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(SceneDev S, CamDev C, Re
     p.tr = p.tg = p.tb = 0.0f;
     p.pixel = 0; p.sample = 0; p.bounce = 0;
     bool have_pixel = false, alive = false, done = false;
-    uint32_t next_sample = 0, item_end = 0, chunk = 0;
+    uint32_t next_sample = 0, item_end = 0, chunk = 0, pix_xy = 0;
     float ar = 0.0f, ag = 0.0f, ab = 0.0f;
 
     for (;;) {
@@ -575,7 +578,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(SceneDev S, CamDev C, Re
             }
             if (!have_pixel) {
                 bool need = true;
-                claim_pixels(need, done, p.pixel, chunk, wave_state, work_counter, P, C);
+                claim_pixels(need, done, p.pixel, pix_xy, chunk, wave_state, work_counter, P, C);
                 if (!done) {
                     have_pixel = true;
                     next_sample = P.sample_begin + chunk * P.chunk_spp;
@@ -653,7 +656,7 @@ __device__ __forceinline__ void trav_begin(const SceneDev& S, const Path& p, Tra
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const float d = df[a];
-        const float i = (fabsf(d) >= 1.0e-18f) ? __frcp_rn(d) : copysignf(1.0e18f, d);
+        const float i = (fabsf(d) >= 1.0e-18f) ? fast_rcp(d) : copysignf(1.0e18f, d);
         T.inv[a] = i;
         T.A[a] = -(of[a] + S.eps) * i;
         T.B[a] = -(of[a] - S.eps) * i;
@@ -779,7 +782,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel_ws(SceneDev S, CamDev C, 
 #pragma unroll
     for (int a = 0; a < 3; ++a) { T.inv[a] = 0.0f; T.A[a] = 0.0f; T.B[a] = 0.0f; }
     bool have_pixel = false, alive = false, done = false;
-    uint32_t next_sample = 0, item_end = 0, chunk = 0;
+    uint32_t next_sample = 0, item_end = 0, chunk = 0, pix_xy = 0;
     float ar = 0.0f, ag = 0.0f, ab = 0.0f;
     const int trav_threshold = int(P.trav_threshold), inner_threshold = int(P.inner_threshold);
 
@@ -806,7 +809,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel_ws(SceneDev S, CamDev C, 
                 }
                 if (!have_pixel) {
                     bool need = true;
-                    claim_pixels(need, done, p.pixel, chunk, wave_state, work_counter, P, C);
+                    claim_pixels(need, done, p.pixel, pix_xy, chunk, wave_state, work_counter, P, C);
                     if (!done) {
                         have_pixel = true;
                         next_sample = P.sample_begin + chunk * P.chunk_spp;
@@ -828,7 +831,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel_ws(SceneDev S, CamDev C, 
             if (alive) {
                 const uint4 r = philox4x32_10(p.pixel, p.sample, fresh ? 0u : p.bounce, 0u, P.key0, P.key1);
                 if (fresh) {
-                    start_path_from(C, p.pixel, p.sample, r, p);
+                    start_path_from(C, p.pixel, pix_xy & 0xffffu, pix_xy >> 16, p.sample, r, p);
                 } else if (!scatter_part(P, p, sf, r)) {
                     alive = false;  // bounded fuzz loop gave up: the path contributes nothing
                 }
@@ -1068,6 +1071,7 @@ size_t stack_bytes(const rt_scene* sc) { return size_t(std::max<uint32_t>(sc->st
 int check_render_args(const rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, const char* who) {
     if (!scene || !cam || !opts) return fail(RT_ERR_INVALID_ARGUMENT, "%s: null argument", who);
     if (cam->horiz_res == 0 || cam->vert_res == 0) return fail(RT_ERR_INVALID_ARGUMENT, "%s: zero resolution", who);
+    if (cam->horiz_res > 65535u || cam->vert_res > 65535u) return fail(RT_ERR_LIMIT, "%s: a frame side above 65535 pixels", who);
     if (uint64_t(cam->horiz_res) * cam->vert_res > 0x7fffffffull / 64)
         return fail(RT_ERR_LIMIT, "%s: more than 2^25 pixels", who);
     if (opts->sample_end <= opts->sample_begin)
