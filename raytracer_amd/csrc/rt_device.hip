@@ -62,6 +62,15 @@ struct SceneDev {
     float eps;              // origin widening for the f32 descent
 };
 
+// The per-primitive tables a kernel reads while shading: the HBM copies, or their LDS copies.
+struct Tables {
+    const double4* sph;
+    const float4* mat;
+    const int32_t* kind;
+    const int32_t* prim_id;
+};
+__device__ __forceinline__ Tables global_tables(const SceneDev& S) { return Tables{S.sph, S.mat, S.kind, S.prim_id}; }
+
 struct CamDev {
     float lookfrom[3], lookat[3], h[3], v[3];
     float aperture, span, inv_w, inv_h;
@@ -107,8 +116,8 @@ __device__ __forceinline__ void sincos_rev(float rev, float* s, float* c) {
 // uniform on the unit sphere: same distribution as random_vec3 (src/materials.rs:150-157)
 __device__ __forceinline__ void unit_sphere(float u0, float u1, float* x, float* y, float* z) {
 #pragma clang fp contract(off)
-    float zz = 1.0f - 2.0f * u0;
-    float r = fast_sqrt(fmaxf(0.0f, 1.0f - zz * zz));
+    float zz = fmaf(-2.0f, u0, 1.0f);
+    float r = fast_sqrt(fmaxf(0.0f, fmaf(-zz, zz, 1.0f)));
     float s, c;
     sincos_rev(u1, &s, &c);
     *x = r * c;
@@ -308,12 +317,12 @@ __device__ __forceinline__ void camera_ray_from(const CamDev& C, uint32_t i, uin
     float s, c;
     sincos_rev(0.25f * u01(r.y), &s, &c);
     const float la = C.aperture * (rad * c), lb = C.aperture * (rad * s);
-    const float gh = (-0.5f + float(i) * C.inv_w) * C.span + u01(r.z) * C.inv_w;
-    const float gv = (0.5f - float(j) * C.inv_h) * C.span + u01(r.w) * C.inv_h;
+    const float gh = fmaf(fmaf(float(i), C.inv_w, -0.5f), C.span, u01(r.z) * C.inv_w);
+    const float gv = fmaf(fmaf(-float(j), C.inv_h, 0.5f), C.span, u01(r.w) * C.inv_h);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        o[a] = C.lookfrom[a] + la * C.h[a] + lb * C.v[a];
-        d[a] = (C.lookat[a] + gh * C.h[a] + gv * C.v[a]) - o[a];
+        o[a] = fmaf(lb, C.v[a], fmaf(la, C.h[a], C.lookfrom[a]));
+        d[a] = fmaf(gv, C.v[a], fmaf(gh, C.h[a], C.lookat[a])) - o[a];
     }
     normalize3(d[0], d[1], d[2]);
 }
@@ -372,15 +381,15 @@ struct Surf {
 // it ends here with the colour (Lr,Lg,Lb): a miss (sky), an emitter, or the depth limit.  At the depth
 // limit the reference still calls scatter and then drops the ray (src/lib.rs:105, :134); with a
 // counter-based RNG that call has no effect on anything, so it is not made.
-__device__ __forceinline__ bool hit_part(const SceneDev& S, const RenderParams& P, Path& p, const Best& hit, Surf& sf,
-                                         float& Lr, float& Lg, float& Lb) {
+__device__ __forceinline__ bool hit_part(const SceneDev& S, const Tables& Tb, const RenderParams& P, Path& p, const Best& hit,
+                                         Surf& sf, float& Lr, float& Lg, float& Lb) {
 #pragma clang fp contract(off)
     const float dxf = float(p.dx), dyf = float(p.dy), dzf = float(p.dz);
     if (hit.k < 0) {  // src/lib.rs:117-130
-        const float t = 0.5f * (dyf + 1.0f);
-        Lr = p.tr * ((1.0f - t) + t * 0.5f);
-        Lg = p.tg * ((1.0f - t) + t * 0.7f);
-        Lb = p.tb * ((1.0f - t) + t * 1.0f);
+        const float t = fmaf(0.5f, dyf, 0.5f);
+        Lr = p.tr * fmaf(t, -0.5f, 1.0f);  // (1-t)*1 + t*0.5
+        Lg = p.tg * fmaf(t, -0.3f, 1.0f);  // (1-t)*1 + t*0.7
+        Lb = p.tb;                         // (1-t)*1 + t*1
         return false;
     }
     const int32_t k = hit.k;
@@ -389,7 +398,7 @@ __device__ __forceinline__ bool hit_part(const SceneDev& S, const RenderParams& 
     sf.hz = p.oz + hit.t * p.dz;
     float lx, ly, lz;  // obj_relative_loc (src/lib.rs:106-113)
     if (k < S.n_spheres) {
-        const double4 s = S.sph[k];
+        const double4 s = Tb.sph[k];
         const float rx = float(sf.hx - s.x), ry = float(sf.hy - s.y), rz = float(sf.hz - s.z);
         const float inv_r = fast_rcp(float(s.w));
         sf.nx = rx * inv_r; sf.ny = ry * inv_r; sf.nz = rz * inv_r;  // src/geometry.rs:123-125
@@ -399,11 +408,11 @@ __device__ __forceinline__ bool hit_part(const SceneDev& S, const RenderParams& 
         sf.nx = float(dd.nx); sf.ny = float(dd.ny); sf.nz = float(dd.nz);  // src/geometry.rs:141-143
         lx = float(sf.hx - dd.cx); ly = float(sf.hy - dd.cy); lz = float(sf.hz - dd.cz);
     }
-    const int32_t kind_word = S.kind[k];
-    const float4 m = S.mat[k];
+    const int32_t kind_word = Tb.kind[k];
+    const float4 m = Tb.mat[k];
     sf.kind = kind_word & 0xff;
     sf.w = m.w;
-    sf.ddn = dxf * sf.nx + dyf * sf.ny + dzf * sf.nz;
+    sf.ddn = fmaf(dzf, sf.nz, fmaf(dyf, sf.ny, dxf * sf.nx));
     if (sf.kind == RT_MAT_EMITTER) {  // src/lib.rs:101-104: the throughput is dropped
         const float c = fabsf(sf.ddn);
         Lr = m.x * c; Lg = m.y * c; Lb = m.z * c;
@@ -432,37 +441,39 @@ __device__ __forceinline__ bool scatter_part(const RenderParams& P, Path& p, con
     float sx, sy, sz;  // scattered direction before Ray::new normalises it
     if (sf.kind == RT_MAT_DIELECTRIC) {  // src/materials.rs:96-121
         const float inc_cos = ddn;
-        const float px = dxf - inc_cos * nx, py = dyf - inc_cos * ny, pz = dzf - inc_cos * nz;
+        const float px = fmaf(-inc_cos, nx, dxf), py = fmaf(-inc_cos, ny, dyf), pz = fmaf(-inc_cos, nz, dzf);
         const bool entering = __float_as_uint(inc_cos) >> 31;  // signum < 0 (also for -0.0)
         const float ratio = entering ? fast_rcp(sf.w) : sf.w;
         const float qx = ratio * px, qy = ratio * py, qz = ratio * pz;
-        const float sin2 = qx * qx + qy * qy + qz * qz;
+        const float sin2 = fmaf(qz, qz, fmaf(qy, qy, qx * qx));
         bool reflect = sin2 > 1.0f;
         if (!reflect) {  // the Schlick draw counts only when sin2 <= 1 (`||` short-circuits)
             float r0f = (1.0f - ratio) * fast_rcp(1.0f + ratio);
             r0f = r0f * r0f;
             const float x = 1.0f - fabsf(inc_cos);
-            const float reflectance = r0f + (1.0f - r0f) * (x * x * x * x * x);
+            const float x2 = x * x;
+            const float reflectance = fmaf(1.0f - r0f, x2 * x2 * x, r0f);
             reflect = u01(r0.z) < reflectance;
         }
         if (reflect) {
-            sx = px - inc_cos * nx; sy = py - inc_cos * ny; sz = pz - inc_cos * nz;
+            sx = fmaf(-inc_cos, nx, px); sy = fmaf(-inc_cos, ny, py); sz = fmaf(-inc_cos, nz, pz);
         } else {
             const float sc_cos = (entering ? -1.0f : 1.0f) * fast_sqrt(1.0f - sin2);
-            sx = qx + sc_cos * nx; sy = qy + sc_cos * ny; sz = qz + sc_cos * nz;
+            sx = fmaf(sc_cos, nx, qx); sy = fmaf(sc_cos, ny, qy); sz = fmaf(sc_cos, nz, qz);
         }
     } else {
         float vx, vy, vz;
         unit_sphere(u01(r0.x), u01(r0.y), &vx, &vy, &vz);
         if (sf.kind == RT_MAT_METAL) {  // src/materials.rs:86-95, fuzzify :141-148
-            const float rx = dxf - 2.0f * ddn * nx, ry = dyf - 2.0f * ddn * ny, rz = dzf - 2.0f * ddn * nz;
-            sx = rx + sf.w * vx; sy = ry + sf.w * vy; sz = rz + sf.w * vz;
+            const float m2 = -2.0f * ddn;
+            const float rx = fmaf(m2, nx, dxf), ry = fmaf(m2, ny, dyf), rz = fmaf(m2, nz, dzf);
+            sx = fmaf(sf.w, vx, rx); sy = fmaf(sf.w, vy, ry); sz = fmaf(sf.w, vz, rz);
             uint32_t attempt = 1;
-            while (!(sx * nx + sy * ny + sz * nz > 0.0f)) {
+            while (!(fmaf(sz, nz, fmaf(sy, ny, sx * nx)) > 0.0f)) {
                 if (attempt >= uint32_t(kFuzzMaxAttempts)) return false;  // the reference would recurse without bound
                 const uint4 r = philox4x32_10(p.pixel, p.sample, p.bounce, attempt, P.key0, P.key1);
                 unit_sphere(u01(r.x), u01(r.y), &vx, &vy, &vz);
-                sx = rx + sf.w * vx; sy = ry + sf.w * vy; sz = rz + sf.w * vz;
+                sx = fmaf(sf.w, vx, rx); sy = fmaf(sf.w, vy, ry); sz = fmaf(sf.w, vz, rz);
                 ++attempt;
             }
         } else {  // Diffuse and TextureMap, src/materials.rs:82-85, :122-125
@@ -483,7 +494,8 @@ __device__ __forceinline__ bool advance(const SceneDev& S, const RenderParams& P
     const Best hit = closest_hit<false>(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, stk);
     if (hit_id) { *hit_id = hit.k < 0 ? -1 : hit.id; *hit_t = hit.t; }
     Surf sf;
-    if (!hit_part(S, P, p, hit, sf, Lr, Lg, Lb)) return false;
+    const Tables Tb = global_tables(S);
+    if (!hit_part(S, Tb, P, p, hit, sf, Lr, Lg, Lb)) return false;
     if (!scatter_part(P, p, sf, philox4x32_10(p.pixel, p.sample, p.bounce, 0u, P.key0, P.key1))) {
         Lr = Lg = Lb = 0.0f;
         return false;
@@ -619,8 +631,8 @@ __global__ __launch_bounds__(kBlock) void render_kernel(SceneDev S, CamDev C, Re
 //     once and sends them back into the descent.
 // With LDS16 the whole scene is staged in LDS: boxes as f16 (rounded outward, so
 // the descent stays conservative), child links as int16, spheres as f64.
-constexpr int kTravThreshold = 8;
-constexpr int kInnerThreshold = 2;
+constexpr int kTravThreshold = 12;
+constexpr int kInnerThreshold = 8;
 
 struct Node16 {       // 32 bytes: two 16-byte LDS reads
     uint16_t h[12];   // lo0.xyz hi0.xyz lo1.xyz hi1.xyz as IEEE half bits
@@ -726,12 +738,12 @@ __device__ __forceinline__ void inner_step(const SceneDev& S, const uint4* lds_q
 }
 
 template <bool LDS16, int BLOCK>
-__device__ __forceinline__ void leaf_step(const SceneDev& S, const double4* lds_sph, const Path& p, Trav& T, int32_t* stk) {
+__device__ __forceinline__ void leaf_step(const Tables& Tb, const Path& p, Trav& T, int32_t* stk) {
     const int32_t k = ~T.node;
-    const double4 s = LDS16 ? lds_sph[k] : S.sph[k];
+    const double4 s = Tb.sph[k];
     double t;
     if (sphere_intersect_f64(s.x, s.y, s.z, s.w, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, &t)) {
-        consider(T.best, t, k, S.prim_id[k]);
+        consider(T.best, t, k, Tb.prim_id[k]);
         T.tmax = float(T.best.t) * (1.0f + 4.0e-7f);
     }
     if (T.sp > 0) {
@@ -752,11 +764,16 @@ __global__ __launch_bounds__(BLOCK) void render_kernel_ws(SceneDev S, CamDev C, 
                                                           uint32_t* __restrict__ work_counter) {
     uint32_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     extern __shared__ uint4 lds_raw[];
-    // LDS layout (16-byte units): [q0: n_nodes][q1: n_nodes][spheres: 2*n_spheres][stack: stack_depth*BLOCK/4]
+    // LDS layout (16-byte units): [q0: n_nodes][q1: n_nodes][spheres: 2*n_spheres][mat: n_prims]
+    //                             [kind: n_prims/4][prim_id: n_prims/4][stack: stack_depth*BLOCK/4][hand-out state]
+    const int32_t n_prims = S.n_spheres + S.n_discs, quads = (n_prims + 3) / 4;
     uint4* lds_q0 = lds_raw;
     uint4* lds_q1 = lds_raw + (LDS16 ? S.n_nodes : 0);
-    double4* lds_sph = reinterpret_cast<double4*>(lds_raw + (LDS16 ? 2 * S.n_nodes : 0));
-    int32_t* stk0 = reinterpret_cast<int32_t*>(lds_raw + (LDS16 ? 2 * S.n_nodes + 2 * S.n_spheres : 0));
+    uint4* lds_sph = lds_raw + (LDS16 ? 2 * S.n_nodes : 0);
+    uint4* lds_mat = lds_sph + (LDS16 ? 2 * S.n_spheres : 0);
+    uint4* lds_kind = lds_mat + (LDS16 ? n_prims : 0);
+    uint4* lds_id = lds_kind + (LDS16 ? quads : 0);
+    int32_t* stk0 = reinterpret_cast<int32_t*>(lds_id + (LDS16 ? quads : 0));
     int32_t* stk = stk0 + threadIdx.x;
     volatile uint32_t* wave_state = reinterpret_cast<uint32_t*>(stk0 + stack_depth * BLOCK) + 2 * (threadIdx.x >> 6);
     if ((threadIdx.x & 63) == 0) { wave_state[0] = 0; wave_state[1] = 64; }
@@ -764,10 +781,18 @@ __global__ __launch_bounds__(BLOCK) void render_kernel_ws(SceneDev S, CamDev C, 
         const uint4* src = reinterpret_cast<const uint4*>(nodes16);
         for (int32_t i = threadIdx.x; i < S.n_nodes; i += BLOCK) { lds_q0[i] = src[2 * i]; lds_q1[i] = src[2 * i + 1]; }
         const uint4* ssrc = reinterpret_cast<const uint4*>(S.sph);
-        uint4* sdst = reinterpret_cast<uint4*>(lds_sph);
-        for (int32_t i = threadIdx.x; i < 2 * S.n_spheres; i += BLOCK) sdst[i] = ssrc[i];
+        for (int32_t i = threadIdx.x; i < 2 * S.n_spheres; i += BLOCK) lds_sph[i] = ssrc[i];
+        const uint4* msrc = reinterpret_cast<const uint4*>(S.mat);
+        for (int32_t i = threadIdx.x; i < n_prims; i += BLOCK) lds_mat[i] = msrc[i];
+        // the int tables are copied word by word: their length need not be a multiple of four
+        int32_t* kdst = reinterpret_cast<int32_t*>(lds_kind);
+        int32_t* idst = reinterpret_cast<int32_t*>(lds_id);
+        for (int32_t i = threadIdx.x; i < n_prims; i += BLOCK) { kdst[i] = S.kind[i]; idst[i] = S.prim_id[i]; }
         __syncthreads();
     }
+    const Tables Tb = LDS16 ? Tables{reinterpret_cast<const double4*>(lds_sph), reinterpret_cast<const float4*>(lds_mat),
+                                     reinterpret_cast<const int32_t*>(lds_kind), reinterpret_cast<const int32_t*>(lds_id)}
+                            : global_tables(S);
 
     Path p;
     p.ox = p.oy = p.oz = 0.0;
@@ -797,7 +822,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel_ws(SceneDev S, CamDev C, 
             bool fresh = false;
             if (alive) {
                 float Lr, Lg, Lb;
-                if (!hit_part(S, P, p, T.best, sf, Lr, Lg, Lb)) {
+                if (!hit_part(S, Tb, P, p, T.best, sf, Lr, Lg, Lb)) {
                     ar += Lr; ag += Lg; ab += Lb;
                     alive = false;
                 }
@@ -853,7 +878,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel_ws(SceneDev S, CamDev C, 
             }
             if (__any(T.node < 0 && T.node != kLeafSentinel)) {
                 if (STATS) { st[2]++; if (T.node < 0 && T.node != kLeafSentinel) st[3]++; }
-                if (T.node < 0 && T.node != kLeafSentinel) leaf_step<LDS16, BLOCK>(S, lds_sph, p, T, stk);
+                if (T.node < 0 && T.node != kLeafSentinel) leaf_step<LDS16, BLOCK>(Tb, p, T, stk);
             } else {
                 // fewer than kInnerThreshold lanes on inner nodes and nobody on a leaf: step them anyway
                 if (STATS) { st[0]++; if (T.node >= 0) st[1]++; }
@@ -1248,7 +1273,8 @@ int rt_scene_create(const rt_hittable* hittables, size_t n_hittables, const rt_t
     int rc;
     // f16 copy of the nodes for the LDS-resident kernel: small scenes only (int16 child links, LDS capacity)
     {
-        const size_t scene_bytes = 32 * bvh.nodes.size() + 32 * n_s;
+        const size_t n_prims = n_s + n_d;
+        const size_t scene_bytes = 32 * bvh.nodes.size() + 32 * n_s + 16 * n_prims + 2 * 16 * ((n_prims + 3) / 4);
         const size_t with_stack = scene_bytes + size_t(sc->stack_depth) * 512 * sizeof(int32_t);
         if (n_s > 0 && n_s <= 32767 && bvh.nodes.size() <= 32767 && with_stack <= 80 * 1024) {
             std::vector<Node16> n16(bvh.nodes.size());

@@ -1,13 +1,14 @@
 #!/bin/bash
 # PMC passes over `bench.py` (one rocprofv3 run per pass; counters never combined with tracing).
-# usage: scripts/pmc_passes.sh <outdir> [bench args...]
+# usage: scripts/pmc_passes.sh <outdir>            (profiles `python3 bench.py --steps 1 --warmup 0 --cpu-seconds 0`)
+#        PMC_CMD="scripts/run_config.py c5 --steps 1" scripts/pmc_passes.sh <outdir>
 set -u
 out=$1; shift
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 pass() {
   name=$1; shift
-  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$out/$name" -- python3 bench.py --steps 1 --warmup 0 --cpu-seconds 0 ${BENCH_ARGS:-} > "$out/$name.log" 2>&1 || { echo "pass $name failed"; tail -3 "$out/$name.log"; return 1; }
+  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$out/$name" -- python3 ${PMC_CMD:-bench.py --steps 1 --warmup 0 --cpu-seconds 0} > "$out/$name.log" 2>&1 || { echo "pass $name failed"; tail -3 "$out/$name.log"; return 1; }
 }
 pass sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE &&
 pass sq2 SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_INT32 &&
