@@ -648,6 +648,7 @@ struct Trav {
     float tmax;
     int32_t node;
     int32_t sp;
+    int32_t top;  // top of the stack lives in a register: a pop does not wait for LDS
     Best best;
 };
 
@@ -655,7 +656,8 @@ __device__ __forceinline__ void trav_begin(const SceneDev& S, const Path& p, Tra
     T.best.t = 0.0;
     T.best.k = -1;
     T.best.id = 0x7fffffff;
-    T.sp = 0;
+    T.sp = 1;
+    T.top = kLeafSentinel;
     for (int32_t i = 0; i < S.n_discs; ++i) {
         double t;
         if (disc_intersect_f64(S.discs[i], p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, &t))
@@ -691,24 +693,29 @@ __device__ __forceinline__ void slab2(const Trav& T, float lo0x, float lo0y, flo
     *ex1 = fminf(fminf(fmaxf(u0x, u1x), fmaxf(u0y, u1y)), fminf(fmaxf(u0z, u1z), T.tmax));
 }
 
+// The stack keeps its top in T.top and the rest in LDS (stk[level * BLOCK], this lane's column).  A traversal
+// starts with sp == 1 and top == kLeafSentinel above slot 0, which the kernel fills with kLeafSentinel once and no
+// push ever writes (pushes store at sp >= 1): popping the empty stack yields the sentinel, which ends the
+// traversal, without a test of sp, and the lane does not pop again before trav_begin resets it.
+template <int BLOCK>
+__device__ __forceinline__ void pop(Trav& T, int32_t* stk) {
+    T.node = T.top;
+    --T.sp;
+    T.top = stk[T.sp * BLOCK];
+}
+
 template <int BLOCK>
 __device__ __forceinline__ void descend(Trav& T, float en0, float ex0, float en1, float ex1, int32_t c0, int32_t c1,
                                         int32_t* stk) {
     const bool h0 = en0 <= ex0, h1 = en1 <= ex1;
-    if (h0 && h1) {
-        const bool swap = en1 < en0;
-        stk[T.sp * BLOCK] = swap ? c0 : c1;
-        ++T.sp;
-        T.node = swap ? c1 : c0;
-    } else if (h0) {
-        T.node = c0;
-    } else if (h1) {
-        T.node = c1;
-    } else if (T.sp > 0) {
-        --T.sp;
-        T.node = stk[T.sp * BLOCK];
+    const bool both = h0 && h1, swap = en1 < en0;
+    if (both) stk[T.sp * BLOCK] = T.top;
+    if (h0 || h1) {
+        T.node = (h0 && !(h1 && swap)) ? c0 : c1;
+        T.top = both ? (swap ? c0 : c1) : T.top;
+        T.sp += both ? 1 : 0;
     } else {
-        T.node = kLeafSentinel;
+        pop<BLOCK>(T, stk);
     }
 }
 
@@ -737,6 +744,107 @@ __device__ __forceinline__ void inner_step(const SceneDev& S, const uint4* lds_q
     descend<BLOCK>(T, en0, ex0, en1, ex1, c0, c1, stk);
 }
 
+// LDS byte address of an object in dynamic shared memory
+__device__ __forceinline__ uint32_t lds_address(const void* p) {
+    return uint32_t(uintptr_t((__attribute__((address_space(3))) const void*)p));
+}
+
+// The inner-node loop of the LDS-resident f16 tree, written out in gfx950 assembly:
+//     while (at least `thr` lanes of the wave stand on an inner node) those lanes take one inner_step
+// It is the same arithmetic as slab2/descend above (f16 bounds fed to v_fma_mix_f32, the lane's stack column in
+// LDS with its top in a register).  What the compiler's version of this loop spends and this one does not: about
+// sixteen register copies per turn for the loop-carried values, and a wait for the popped stack entry before the
+// next node can be fetched (here the pop's ds_read is only waited for together with the next node's data).
+// Fixed registers: v112-v127 and s88-s99 are scratch of this block (the 128-bit node halves need named registers,
+// inline-asm operands cannot name the dwords of a tuple).  EXEC is narrowed inside and restored before leaving.
+template <int BLOCK>
+__device__ __forceinline__ void inner_loop_lds16(Trav& T, uint32_t q0_addr, uint32_t q1_addr, uint32_t stk_addr,
+                                                 int32_t thr) {
+    static_assert(BLOCK == 512 || BLOCK == 256, "stack column stride");
+    constexpr int kShift = (BLOCK == 512) ? 11 : 10;  // log2(BLOCK * sizeof(int32_t))
+    int32_t lanes_on_inner;
+    asm volatile(
+        "1:\n\t"
+        "v_cmp_lt_i32_e32 vcc, -1, %[node]\n\t"
+        "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
+        "s_cmp_lt_i32 %[cnt], %[thr]\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_and_saveexec_b64 s[88:89], vcc\n\t"
+        "v_lshl_add_u32 v112, %[node], 4, %[q0]\n\t"
+        "v_lshl_add_u32 v113, %[node], 4, %[q1]\n\t"
+        "ds_read_b128 v[120:123], v112\n\t"
+        "ds_read_b128 v[124:127], v113\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        // child 0: v120 = lo.x lo.y | v121 = lo.z hi.x | v122 = hi.y hi.z
+        "v_fma_mix_f32 v112, v120, %[ix], %[ax] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 v113, v121, %[ix], %[bx] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 v114, v120, %[iy], %[ay] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 v115, v122, %[iy], %[by] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 v116, v121, %[iz], %[az] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 v117, v122, %[iz], %[bz] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_min_f32_e32 v118, v112, v113\n\t"
+        "v_max_f32_e32 v112, v112, v113\n\t"
+        "v_min_f32_e32 v113, v114, v115\n\t"
+        "v_max_f32_e32 v114, v114, v115\n\t"
+        "v_min_f32_e32 v115, v116, v117\n\t"
+        "v_max_f32_e32 v116, v116, v117\n\t"
+        "v_max_f32_e32 v115, 0, v115\n\t"
+        "v_min_f32_e32 v116, v116, %[tmax]\n\t"
+        "v_max3_f32 v118, v118, v113, v115\n\t"   // entry parameter of child 0
+        "v_min3_f32 v119, v112, v114, v116\n\t"   // exit parameter of child 0
+        // child 1: v123 = lo.x lo.y | v124 = lo.z hi.x | v125 = hi.y hi.z
+        "v_fma_mix_f32 v112, v123, %[ix], %[ax] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 v113, v124, %[ix], %[bx] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 v114, v123, %[iy], %[ay] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 v115, v125, %[iy], %[by] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 v116, v124, %[iz], %[az] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 v117, v125, %[iz], %[bz] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_min_f32_e32 v122, v112, v113\n\t"
+        "v_max_f32_e32 v112, v112, v113\n\t"
+        "v_min_f32_e32 v113, v114, v115\n\t"
+        "v_max_f32_e32 v114, v114, v115\n\t"
+        "v_min_f32_e32 v115, v116, v117\n\t"
+        "v_max_f32_e32 v116, v116, v117\n\t"
+        "v_max_f32_e32 v115, 0, v115\n\t"
+        "v_min_f32_e32 v116, v116, %[tmax]\n\t"
+        "v_max3_f32 v122, v122, v113, v115\n\t"   // entry parameter of child 1
+        "v_min3_f32 v127, v112, v114, v116\n\t"   // exit parameter of child 1
+        // v126 = child links: c0 in the low half, c1 in the high half, both signed
+        "v_bfe_i32 v120, v126, 0, 16\n\t"
+        "v_ashrrev_i32_e32 v121, 16, v126\n\t"
+        "v_cmp_le_f32_e64 s[90:91], v118, v119\n\t"   // h0
+        "v_cmp_le_f32_e64 s[92:93], v122, v127\n\t"   // h1
+        "v_cmp_lt_f32_e64 s[94:95], v122, v118\n\t"   // child 1 is entered first
+        "s_and_b64 s[96:97], s[90:91], s[92:93]\n\t"  // both
+        "s_or_b64 s[98:99], s[90:91], s[92:93]\n\t"   // any
+        "s_and_b64 s[94:95], s[94:95], s[92:93]\n\t"
+        "s_andn2_b64 s[94:95], s[90:91], s[94:95]\n\t"  // go to c0: h0 and not (h1 and child 1 first)
+        "s_andn2_b64 s[98:99], exec, s[98:99]\n\t"      // none
+        "v_cndmask_b32_e64 %[node], v121, v120, s[94:95]\n\t"
+        "v_cndmask_b32_e64 v112, v120, v121, s[94:95]\n\t"  // the other child, pushed where both are hit
+        "s_mov_b64 exec, s[96:97]\n\t"
+        "v_lshl_add_u32 v113, %[sp], %[shift], %[stk]\n\t"
+        "ds_write_b32 v113, %[top]\n\t"
+        "v_add_u32_e32 %[sp], 1, %[sp]\n\t"
+        "v_mov_b32_e32 %[top], v112\n\t"
+        "s_mov_b64 exec, s[98:99]\n\t"
+        "v_mov_b32_e32 %[node], %[top]\n\t"
+        "v_add_u32_e32 %[sp], -1, %[sp]\n\t"
+        "v_lshl_add_u32 v113, %[sp], %[shift], %[stk]\n\t"
+        "ds_read_b32 %[top], v113\n\t"
+        "s_mov_b64 exec, s[88:89]\n\t"
+        "s_branch 1b\n\t"
+        "2:\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        : [node] "+v"(T.node), [sp] "+v"(T.sp), [top] "+v"(T.top), [cnt] "=&s"(lanes_on_inner)
+        : [ix] "v"(T.inv[0]), [iy] "v"(T.inv[1]), [iz] "v"(T.inv[2]), [ax] "v"(T.A[0]), [ay] "v"(T.A[1]),
+          [az] "v"(T.A[2]), [bx] "v"(T.B[0]), [by] "v"(T.B[1]), [bz] "v"(T.B[2]), [tmax] "v"(T.tmax),
+          [stk] "v"(stk_addr), [q0] "s"(q0_addr), [q1] "s"(q1_addr), [thr] "s"(thr), [shift] "n"(kShift)
+        : "memory", "vcc", "scc", "v112", "v113", "v114", "v115", "v116", "v117",
+          "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "s88", "s89", "s90", "s91",
+          "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
+}
+
 template <bool LDS16, int BLOCK>
 __device__ __forceinline__ void leaf_step(const Tables& Tb, const Path& p, Trav& T, int32_t* stk) {
     const int32_t k = ~T.node;
@@ -746,12 +854,7 @@ __device__ __forceinline__ void leaf_step(const Tables& Tb, const Path& p, Trav&
         consider(T.best, t, k, Tb.prim_id[k]);
         T.tmax = float(T.best.t) * (1.0f + 4.0e-7f);
     }
-    if (T.sp > 0) {
-        --T.sp;
-        T.node = stk[T.sp * BLOCK];
-    } else {
-        T.node = kLeafSentinel;
-    }
+    pop<BLOCK>(T, stk);
 }
 
 // STATS (diagnostic build only): counts, per phase, wave-level turns and the lanes that took part, into
@@ -777,6 +880,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel_ws(SceneDev S, CamDev C, 
     int32_t* stk = stk0 + threadIdx.x;
     volatile uint32_t* wave_state = reinterpret_cast<uint32_t*>(stk0 + stack_depth * BLOCK) + 2 * (threadIdx.x >> 6);
     if ((threadIdx.x & 63) == 0) { wave_state[0] = 0; wave_state[1] = 64; }
+    stk[0] = kLeafSentinel;
     if (LDS16) {
         const uint4* src = reinterpret_cast<const uint4*>(nodes16);
         for (int32_t i = threadIdx.x; i < S.n_nodes; i += BLOCK) { lds_q0[i] = src[2 * i]; lds_q1[i] = src[2 * i + 1]; }
@@ -801,7 +905,8 @@ __global__ __launch_bounds__(BLOCK) void render_kernel_ws(SceneDev S, CamDev C, 
     p.pixel = 0; p.sample = 0; p.bounce = 0;
     Trav T;
     T.node = kLeafSentinel;
-    T.sp = 0;
+    T.sp = 1;
+    T.top = kLeafSentinel;
     T.tmax = 0.0f;
     T.best.t = 0.0; T.best.k = -1; T.best.id = 0;
 #pragma unroll
@@ -810,6 +915,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel_ws(SceneDev S, CamDev C, 
     uint32_t next_sample = 0, item_end = 0, chunk = 0, pix_xy = 0;
     float ar = 0.0f, ag = 0.0f, ab = 0.0f;
     const int trav_threshold = int(P.trav_threshold), inner_threshold = int(P.inner_threshold);
+    const uint32_t q0_addr = lds_address(lds_q0), q1_addr = lds_address(lds_q1), stk_addr = lds_address(stk);
 
     for (;;) {
         // ---- shade phase: every lane that is not descending.  One Philox block per lane and turn:
@@ -872,9 +978,13 @@ __global__ __launch_bounds__(BLOCK) void render_kernel_ws(SceneDev S, CamDev C, 
             const bool someone_waits = __any(!descending && !done);
             if (n_desc == 0 || (n_desc < trav_threshold && someone_waits)) break;
             if (STATS) st[7]++;
-            while (int(__popcll(__ballot(T.node >= 0))) >= inner_threshold) {
-                if (STATS) { st[0]++; if (T.node >= 0) st[1]++; }
-                if (T.node >= 0) inner_step<LDS16, BLOCK>(S, lds_q0, lds_q1, T, stk);
+            if (LDS16 && !STATS) {
+                inner_loop_lds16<BLOCK>(T, q0_addr, q1_addr, stk_addr, inner_threshold);
+            } else {
+                while (int(__popcll(__ballot(T.node >= 0))) >= inner_threshold) {
+                    if (STATS) { st[0]++; if (T.node >= 0) st[1]++; }
+                    if (T.node >= 0) inner_step<LDS16, BLOCK>(S, lds_q0, lds_q1, T, stk);
+                }
             }
             if (__any(T.node < 0 && T.node != kLeafSentinel)) {
                 if (STATS) { st[2]++; if (T.node < 0 && T.node != kLeafSentinel) st[3]++; }
@@ -1206,7 +1316,7 @@ int rt_scene_create(const rt_hittable* hittables, size_t n_hittables, const rt_t
     while ((size_t(1) << lg) < sphere_ids.size()) ++lg;
     BuiltBvh bvh;
     build_bvh(sph4.data(), sphere_ids.size(), lg + 7, &bvh);
-    sc->stack_depth = bvh.depth + 1;
+    sc->stack_depth = bvh.depth + 2;  // one pending entry per level, plus slot 0 (the sentinel below every stack)
     double bound = 0.0;
     for (int a = 0; a < 3; ++a) bound = std::max(bound, std::max(std::fabs(bvh.scene_lo[a]), std::fabs(bvh.scene_hi[a])));
 

@@ -40,7 +40,7 @@ def test_scene_info(scene1):
     i = scene1.info
     assert i["n_hittables"] == 488 and i["n_spheres"] == 488 and i["n_discs"] == 0
     assert i["n_nodes"] == 487  # one sphere per leaf: N-1 inner nodes
-    assert 9 <= i["bvh_depth"] <= 16 and i["stack_depth"] == i["bvh_depth"] + 1
+    assert 9 <= i["bvh_depth"] <= 16 and i["stack_depth"] == i["bvh_depth"] + 2
 
 
 def test_primary_hits_match_golden_dump(scene1):
