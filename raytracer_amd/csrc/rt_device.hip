@@ -750,7 +750,8 @@ __device__ __forceinline__ uint32_t lds_address(const void* p) {
 }
 
 // The inner-node loop of the LDS-resident f16 tree, written out in gfx950 assembly:
-//     while (at least `thr` lanes of the wave stand on an inner node) those lanes take one inner_step
+//     while (at least `thr` lanes of the wave stand on an inner node, or some do and none waits at a leaf)
+//         those lanes take one inner_step
 // It is the same arithmetic as slab2/descend above (f16 bounds fed to v_fma_mix_f32, the lane's stack column in
 // LDS with its top in a register).  What the compiler's version of this loop spends and this one does not: about
 // sixteen register copies per turn for the loop-carried values, and a wait for the popped stack entry before the
@@ -767,8 +768,14 @@ __device__ __forceinline__ void inner_loop_lds16(Trav& T, uint32_t q0_addr, uint
         "1:\n\t"
         "v_cmp_lt_i32_e32 vcc, -1, %[node]\n\t"
         "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
-        "s_cmp_lt_i32 %[cnt], %[thr]\n\t"
+        "s_cmp_ge_i32 %[cnt], %[thr]\n\t"
+        "s_cbranch_scc1 3f\n\t"
+        "s_cmp_eq_u32 %[cnt], 0\n\t"
         "s_cbranch_scc1 2f\n\t"
+        "v_cmp_lt_u32_e64 s[90:91], %[sentinel], %[node]\n\t"  // as unsigned: above the sentinel = a leaf
+        "s_cmp_lg_u64 s[90:91], 0\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "3:\n\t"
         "s_and_saveexec_b64 s[88:89], vcc\n\t"
         "v_lshl_add_u32 v112, %[node], 4, %[q0]\n\t"
         "v_lshl_add_u32 v113, %[node], 4, %[q1]\n\t"
@@ -839,7 +846,8 @@ __device__ __forceinline__ void inner_loop_lds16(Trav& T, uint32_t q0_addr, uint
         : [node] "+v"(T.node), [sp] "+v"(T.sp), [top] "+v"(T.top), [cnt] "=&s"(lanes_on_inner)
         : [ix] "v"(T.inv[0]), [iy] "v"(T.inv[1]), [iz] "v"(T.inv[2]), [ax] "v"(T.A[0]), [ay] "v"(T.A[1]),
           [az] "v"(T.A[2]), [bx] "v"(T.B[0]), [by] "v"(T.B[1]), [bz] "v"(T.B[2]), [tmax] "v"(T.tmax),
-          [stk] "v"(stk_addr), [q0] "s"(q0_addr), [q1] "s"(q1_addr), [thr] "s"(thr), [shift] "n"(kShift)
+          [stk] "v"(stk_addr), [q0] "s"(q0_addr), [q1] "s"(q1_addr), [thr] "s"(thr), [sentinel] "s"(kLeafSentinel),
+          [shift] "n"(kShift)
         : "memory", "vcc", "scc", "v112", "v113", "v114", "v115", "v116", "v117",
           "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "s88", "s89", "s90", "s91",
           "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
@@ -849,11 +857,29 @@ template <bool LDS16, int BLOCK>
 __device__ __forceinline__ void leaf_step(const Tables& Tb, const Path& p, Trav& T, int32_t* stk) {
     const int32_t k = ~T.node;
     const double4 s = Tb.sph[k];
+    const int32_t id = Tb.prim_id[k];
+    // sphere_intersect_f64 and consider() with selects instead of branches: the same operations in the same
+    // order (a negative discriminant gives a NaN root, which fails both comparisons below)
+    bool better;
     double t;
-    if (sphere_intersect_f64(s.x, s.y, s.z, s.w, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, &t)) {
-        consider(T.best, t, k, Tb.prim_id[k]);
-        T.tmax = float(T.best.t) * (1.0f + 4.0e-7f);
+    {
+#pragma clang fp contract(off)
+        const double rx = p.ox - s.x, ry = p.oy - s.y, rz = p.oz - s.z;
+        const double b = 2.0 * (rx * p.dx + ry * p.dy + rz * p.dz);
+        const double c = (rx * rx + ry * ry + rz * rz) - s.w * s.w;
+        const double discrm = b * b - 4.0 * c;
+        const double sq = __dsqrt_rn(discrm);
+        const double t_smaller = -0.5 * (b + sq);
+        const double t_larger = t_smaller + sq;
+        const bool near_ok = t_smaller > 0.0;
+        const bool hit = !(discrm < 0.0) && (near_ok || t_larger > 1.0e-6);
+        t = near_ok ? t_smaller : t_larger;
+        better = hit && (T.best.k < 0 || t < T.best.t || (t == T.best.t && id < T.best.id));
     }
+    T.best.t = better ? t : T.best.t;
+    T.best.k = better ? k : T.best.k;
+    T.best.id = better ? id : T.best.id;
+    T.tmax = better ? float(t) * (1.0f + 4.0e-7f) : T.tmax;
     pop<BLOCK>(T, stk);
 }
 
@@ -981,19 +1007,15 @@ __global__ __launch_bounds__(BLOCK) void render_kernel_ws(SceneDev S, CamDev C, 
             if (LDS16 && !STATS) {
                 inner_loop_lds16<BLOCK>(T, q0_addr, q1_addr, stk_addr, inner_threshold);
             } else {
-                while (int(__popcll(__ballot(T.node >= 0))) >= inner_threshold) {
+                for (;;) {
+                    const int n_inner = int(__popcll(__ballot(T.node >= 0)));
+                    if (n_inner < inner_threshold && (n_inner == 0 || __any(T.node < 0 && T.node != kLeafSentinel))) break;
                     if (STATS) { st[0]++; if (T.node >= 0) st[1]++; }
                     if (T.node >= 0) inner_step<LDS16, BLOCK>(S, lds_q0, lds_q1, T, stk);
                 }
             }
-            if (__any(T.node < 0 && T.node != kLeafSentinel)) {
-                if (STATS) { st[2]++; if (T.node < 0 && T.node != kLeafSentinel) st[3]++; }
-                if (T.node < 0 && T.node != kLeafSentinel) leaf_step<LDS16, BLOCK>(Tb, p, T, stk);
-            } else {
-                // fewer than kInnerThreshold lanes on inner nodes and nobody on a leaf: step them anyway
-                if (STATS) { st[0]++; if (T.node >= 0) st[1]++; }
-                if (T.node >= 0) inner_step<LDS16, BLOCK>(S, lds_q0, lds_q1, T, stk);
-            }
+            if (STATS && __any(T.node < 0 && T.node != kLeafSentinel)) { st[2]++; if (T.node < 0 && T.node != kLeafSentinel) st[3]++; }
+            if (T.node < 0 && T.node != kLeafSentinel) leaf_step<LDS16, BLOCK>(Tb, p, T, stk);
         }
     }
     if (STATS) {
