@@ -206,6 +206,46 @@ int rt_trace_path_segments(rt_scene* scene, const rt_camera* cam, const rt_rende
  * per pixel.  Unlike the reference the file is truncated first. */
 int rt_write_ppm(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height);
 
+/* ---- the host side of src/main.rs: scene file, texture images, file output ------------------- */
+
+/* Config of src/config.rs:7-11 read from a scene file (src/main.rs:26-32): "camera" is a SetupCamera
+ * (src/config.rs:13-21) turned into a Camera by SetupCamera::setup (src/config.rs:24-27), "hittables" a
+ * list of {"shape": {"Sphere"|"Disc": {...}}, "material": {"Diffuse"|"Metal"|"Dielectric"|"TextureMap"|
+ * "Emitter": {...}}} in serde's externally tagged form; Vec3 is a 3-array, Color an object {r, g, b}.
+ * "map" of a TextureMap is a PATH whose image is decoded while the scene is read (src/materials.rs:37-46);
+ * a relative path is taken relative to texture_dir (rt_config_load: the directory of the scene file).
+ * Unknown keys are ignored, missing keys and wrong types are errors, as with serde's derive.  Where the
+ * reference panics ("unable to read scene file", "unable to deserialize scene information", "cannot open
+ * file") these return RT_ERR_IO with that text in rt_last_error(). */
+typedef struct rt_config rt_config;
+int rt_config_load(const char* path, rt_config** out);
+int rt_config_parse(const char* json, size_t len, const char* texture_dir, rt_config** out);
+void rt_config_destroy(rt_config* cfg);
+/* Borrowed views into the config (valid until rt_config_destroy); any output pointer may be NULL. */
+int rt_config_view(const rt_config* cfg, rt_camera* camera, const rt_hittable** hittables, size_t* n_hittables,
+                   const rt_texture** textures, size_t* n_textures);
+
+/* image::open of src/materials.rs:37-39 for the one format the reference's scenes use: decodes a baseline
+ * (or extended-sequential Huffman) 8-bit JPEG with 1 or 3 components into RGB8, row 0 = top.  *rgb8 is
+ * allocated by the library; release it with rt_free. */
+int rt_decode_jpeg(const uint8_t* bytes, size_t len, uint8_t** rgb8, uint32_t* width, uint32_t* height);
+int rt_load_jpeg(const char* path, uint8_t** rgb8, uint32_t* width, uint32_t* height);
+void rt_free(void* p);
+
+/* render_into_file (src/lib.rs:137-157) and accel_render_into_file (src/lib.rs:159-184): render `spp`
+ * samples per pixel and append one "r g b\n" line per pixel, rows top to bottom, to the open file
+ * descriptor `fd`, which the caller has positioned after the PPM header (src/main.rs:41-42) — the
+ * reference takes the open File the same way.  `depth` is the literal 10 of src/lib.rs:145 / :172 made
+ * an argument; `seed` keys the sampler.  The scene is built, used and dropped inside the call, as the
+ * reference drops its tree at return (src/lib.rs:162).  The accel variant accepts spheres only: the
+ * reference's cover construction (src/boundingvolume.rs:242-259) has no arm for a Disc. */
+int rt_render_into_file(int fd, const rt_camera* cam, const rt_hittable* hittables, size_t n_hittables,
+                        const rt_texture* textures, size_t n_textures, uint32_t spp, uint32_t depth, uint64_t seed,
+                        int device);
+int rt_accel_render_into_file(int fd, const rt_camera* cam, const rt_hittable* hittables, size_t n_hittables,
+                              const rt_texture* textures, size_t n_textures, uint32_t spp, uint32_t depth, uint64_t seed,
+                              int device);
+
 #ifdef __cplusplus
 }
 #endif

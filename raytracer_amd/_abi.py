@@ -114,6 +114,15 @@ PROTOTYPES = {
     "rt_trace_paths": (_i, [_vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts), _vp, _vp, _sz, _vp]),
     "rt_trace_path_segments": (_i, [_vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts), _vp, _vp, _sz, _vp, _u32, _vp, _vp, _vp]),
     "rt_write_ppm": (_i, [C.c_char_p, _vp, _u32, _u32]),
+    "rt_config_load": (_i, [C.c_char_p, C.POINTER(_vp)]),
+    "rt_config_parse": (_i, [C.c_char_p, _sz, C.c_char_p, C.POINTER(_vp)]),
+    "rt_config_destroy": (None, [_vp]),
+    "rt_config_view": (_i, [_vp, C.POINTER(rt_camera), C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_vp), C.POINTER(_sz)]),
+    "rt_decode_jpeg": (_i, [_vp, _sz, C.POINTER(_vp), C.POINTER(_u32), C.POINTER(_u32)]),
+    "rt_load_jpeg": (_i, [C.c_char_p, C.POINTER(_vp), C.POINTER(_u32), C.POINTER(_u32)]),
+    "rt_free": (None, [_vp]),
+    "rt_render_into_file": (_i, [_i, C.POINTER(rt_camera), _vp, _sz, C.POINTER(rt_texture), _sz, _u32, _u32, _u64, _i]),
+    "rt_accel_render_into_file": (_i, [_i, C.POINTER(rt_camera), _vp, _sz, C.POINTER(rt_texture), _sz, _u32, _u32, _u64, _i]),
 }
 
 

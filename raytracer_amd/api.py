@@ -6,7 +6,6 @@ Names follow the crate: ``Camera.build`` (src/camera.rs:19), ``gen_scene`` /
 arithmetic happens behind ``include/rt_mi355x.h``; this file only marshals.
 """
 import ctypes as C
-import json
 import os
 
 import numpy as np
@@ -276,10 +275,11 @@ def render_into_file(file, cam, scene, spp, depth=REFERENCE_DEPTH, seed=0):
 
 
 class Config:
-    """src/config.rs:7-28 + the serde schema of Shape / Material / Color / Vec3.
+    """src/config.rs:7-28 + the serde schema of Shape / Material / Color / Vec3, read by the library
+    (rt_config_load / rt_config_parse).
 
-    ``"map"`` of a TextureMap is a PATH, loaded while the scene is read
-    (src/materials.rs:37-46); it is resolved against the scene file's directory.
+    ``"map"`` of a TextureMap is a PATH, decoded while the scene is read (src/materials.rs:37-46);
+    a relative path is resolved against the scene file's directory.
     """
 
     def __init__(self, camera, hittable_array, textures):
@@ -287,49 +287,57 @@ class Config:
         self.hittables = hittable_array
         self.textures = textures
 
-    @staticmethod
-    def _color(c):
-        return [c["r"], c["g"], c["b"]]
-
-    @staticmethod
-    def load_texture(path):
-        from PIL import Image  # decoder of convenience; the reference uses the image crate
-
-        with Image.open(path) as im:
-            return np.asarray(im.convert("RGB"), dtype=np.uint8).copy()
+    @classmethod
+    def _from_handle(cls, handle):
+        try:
+            cam = _abi.rt_camera()
+            hp, tp = C.c_void_p(), C.c_void_p()
+            n, nt = C.c_size_t(0), C.c_size_t(0)
+            check(lib.rt_config_view(handle, C.byref(cam), C.byref(hp), C.byref(n), C.byref(tp), C.byref(nt)))
+            items = np.zeros(n.value, dtype=_abi.HITTABLE_DTYPE)
+            if n.value:
+                C.memmove(items.ctypes.data, hp.value, items.nbytes)
+            textures = []
+            tex = C.cast(tp, C.POINTER(_abi.rt_texture))
+            for i in range(nt.value):
+                t = tex[i]
+                buf = (C.c_uint8 * (t.width * t.height * 3)).from_address(t.rgb8)
+                textures.append(np.frombuffer(buf, dtype=np.uint8).reshape(t.height, t.width, 3).copy())
+            return cls(Camera(cam), items, textures)
+        finally:
+            lib.rt_config_destroy(handle)
 
     @classmethod
-    def from_json(cls, path, texture_loader=None):
-        with open(path, "rb") as f:
-            doc = json.loads(f.read())
-        base = os.path.dirname(os.path.abspath(path))
-        loader = texture_loader or cls.load_texture
-        c = doc["camera"]
-        cam = Camera.build(c["lookat"], c["lookfrom"], c["inv_focal_length"], c["aperture"], c["horiz_res"], c["vert_res"])
-        items, textures, tex_index = [], [], {}
-        for entry in doc["hittables"]:
-            (mkind, m), = entry["material"].items()
-            if mkind == "Diffuse":
-                mat = diffuse(cls._color(m["albedo"]))
-            elif mkind == "Metal":
-                mat = metal(cls._color(m["albedo"]), m["fuzz"])
-            elif mkind == "Dielectric":
-                mat = dielectric(m["refractive_index"])
-            elif mkind == "Emitter":
-                mat = emitter(cls._color(m["albedo"]))
-            elif mkind == "TextureMap":
-                p = m["map"] if os.path.isabs(m["map"]) else os.path.join(base, m["map"])
-                if p not in tex_index:
-                    tex_index[p] = len(textures)
-                    textures.append(loader(p))
-                mat = texture_map(tex_index[p], m["orient_up"], m["orient_around"])
-            else:
-                raise RtError(_abi.RT_ERR_UNSUPPORTED, "unknown material %r" % mkind)
-            (skind, s), = entry["shape"].items()
-            if skind == "Sphere":
-                items.append(sphere(s["centre"], s["radius"], mat))
-            elif skind == "Disc":
-                items.append(disc(s["centre"], s["normal"], s["radius"], mat, normalise=False))
-            else:
-                raise RtError(_abi.RT_ERR_UNSUPPORTED, "unknown shape %r" % skind)
-        return cls(cam, hittables(items), textures)
+    def from_json(cls, path):
+        handle = C.c_void_p()
+        check(lib.rt_config_load(os.fsencode(path), C.byref(handle)))
+        return cls._from_handle(handle)
+
+    @classmethod
+    def from_text(cls, text, texture_dir=""):
+        raw = text.encode("utf-8") if isinstance(text, str) else bytes(text)
+        handle = C.c_void_p()
+        check(lib.rt_config_parse(raw, len(raw), os.fsencode(texture_dir), C.byref(handle)))
+        return cls._from_handle(handle)
+
+
+def load_jpeg(path):
+    """image::open of src/materials.rs:37-39 for baseline JPEG files: (H, W, 3) uint8."""
+    p, w, h = C.c_void_p(), C.c_uint32(0), C.c_uint32(0)
+    check(lib.rt_load_jpeg(os.fsencode(path), C.byref(p), C.byref(w), C.byref(h)))
+    try:
+        buf = (C.c_uint8 * (w.value * h.value * 3)).from_address(p.value)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(h.value, w.value, 3).copy()
+    finally:
+        lib.rt_free(p)
+
+
+def decode_jpeg(data):
+    raw = bytes(data)
+    p, w, h = C.c_void_p(), C.c_uint32(0), C.c_uint32(0)
+    check(lib.rt_decode_jpeg(raw, len(raw), C.byref(p), C.byref(w), C.byref(h)))
+    try:
+        buf = (C.c_uint8 * (w.value * h.value * 3)).from_address(p.value)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(h.value, w.value, 3).copy()
+    finally:
+        lib.rt_free(p)

@@ -66,7 +66,7 @@ extern "C" {
 
 const char* rt_last_error(void) { return g_last_error.c_str(); }
 
-uint32_t rt_abi_version(void) { return (1u << 16) | 0u; }
+uint32_t rt_abi_version(void) { return (1u << 16) | 1u; }
 
 int rt_camera_build(const double lookat[3], const double lookfrom[3], double inv_focal_length, double aperture,
                     uint32_t horiz_res, uint32_t vert_res, rt_camera* out) {

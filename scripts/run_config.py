@@ -43,7 +43,7 @@ def main():
         h, tex, spp, depth = rt.gen_scene_grid(1, 1000), [], 64, 50
         cam = rt.Camera.build([0, 0, 0], [130, 40, 30], 1.0, 0.1, 1920, 1080)
     elif a.config == "c1":
-        cfg = rt.Config.from_json(os.path.join(ROOT, "tests", "golden", "scene.json"), texture_loader=lambda p: earth)
+        cfg = rt.Config.from_json(os.path.join(ROOT, "tests", "golden", "scene.json"))
         h, tex, cam, spp, depth = cfg.hittables, cfg.textures, cfg.camera, 10, 10
     else:
         raise SystemExit("unknown config")

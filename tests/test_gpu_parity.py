@@ -272,7 +272,7 @@ def test_bundled_scene_json_disc_emitter_texture(rt, ob, earth_rgb8):
 
     from conftest import GOLDEN
 
-    cfg = rt.Config.from_json(os.path.join(GOLDEN, "scene.json"), texture_loader=lambda p: earth_rgb8)
+    cfg = rt.Config.from_json(os.path.join(GOLDEN, "scene.json"))
     scene = rt.Scene(cfg.hittables, cfg.textures)
     assert scene.info["n_discs"] == 1 and scene.info["n_spheres"] == 4
     oscene = ob.Scene(cfg.hittables, cfg.textures)
@@ -300,7 +300,7 @@ def test_accel_render_refuses_discs_like_the_reference_tree(rt, earth_rgb8, tmp_
 
     from conftest import GOLDEN
 
-    cfg = rt.Config.from_json(os.path.join(GOLDEN, "scene.json"), texture_loader=lambda p: earth_rgb8)
+    cfg = rt.Config.from_json(os.path.join(GOLDEN, "scene.json"))
     scene = rt.Scene(cfg.hittables, cfg.textures)
     cam = rt.Camera.build([0, 0, 1], [0, 1.5, -5], 1.0, 0.1, 16, 16)
     with open(tmp_path / "a.ppm", "w") as f:

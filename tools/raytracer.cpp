@@ -1,0 +1,119 @@
+// raytracer — command-line front end over librt_mi355x.so, in the role of the reference's src/main.rs:
+//   raytracer [-s N | --samples N] [-r | --random]
+// reads ./scene.json (or builds the random scene with -r), renders on one MI355X and writes ./image.ppm.
+// The extra options expose what the reference hard-codes: file names, resolution of the random scene,
+// bounce depth, seeds, device.
+#include <fcntl.h>
+#include <unistd.h>
+
+#include <cerrno>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_mi355x.h"
+
+static void die(const char* what) {
+    std::fprintf(stderr, "raytracer: %s: %s\n", what, rt_last_error());
+    std::exit(101);  // the exit status of a Rust panic
+}
+
+static void usage(int code) {
+    std::printf(
+        "Usage: raytracer [OPTIONS]\n\n"
+        "Options:\n"
+        "  -s, --samples <SAMPLES_PER_PIXEL>  [default: 10]\n"
+        "  -r, --random                       render the random-spheres scene instead of ./scene.json\n"
+        "      --scene <PATH>                 scene file [default: ./scene.json]\n"
+        "      --out <PATH>                   output image [default: ./image.ppm]\n"
+        "      --width <W> --height <H>       resolution of the random scene [default: 512 512]\n"
+        "      --depth <D>                    bounce limit [default: 10]\n"
+        "      --seed <S>                     sampler seed [default: 0]\n"
+        "      --scene-seed <S>               seed of the random scene [default: 1]\n"
+        "      --device <N>                   GPU index [default: 0]\n"
+        "  -h, --help                         Print help\n"
+        "  -V, --version                      Print version\n");
+    std::exit(code);
+}
+
+int main(int argc, char** argv) {
+    uint32_t spp = 10, width = 512, height = 512, depth = 10;  // src/main.rs:65, src/scenegen.rs:76-77, src/lib.rs:172
+    uint64_t seed = 0, scene_seed = 1;
+    bool random_scene = false;
+    int device = 0;
+    std::string scene_path = "./scene.json", out_path = "./image.ppm";  // src/main.rs:26, :38
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto value = [&]() -> const char* {
+            if (i + 1 >= argc) {
+                std::fprintf(stderr, "error: a value is required for '%s' but none was supplied\n", a.c_str());
+                std::exit(2);
+            }
+            return argv[++i];
+        };
+        if (a == "-s" || a == "--samples") spp = uint32_t(std::strtoul(value(), nullptr, 10));
+        else if (a.rfind("--samples=", 0) == 0) spp = uint32_t(std::strtoul(a.c_str() + 10, nullptr, 10));
+        else if (a == "-r" || a == "--random") random_scene = true;
+        else if (a == "--scene") scene_path = value();
+        else if (a == "--out") out_path = value();
+        else if (a == "--width") width = uint32_t(std::strtoul(value(), nullptr, 10));
+        else if (a == "--height") height = uint32_t(std::strtoul(value(), nullptr, 10));
+        else if (a == "--depth") depth = uint32_t(std::strtoul(value(), nullptr, 10));
+        else if (a == "--seed") seed = std::strtoull(value(), nullptr, 10);
+        else if (a == "--scene-seed") scene_seed = std::strtoull(value(), nullptr, 10);
+        else if (a == "--device") device = std::atoi(value());
+        else if (a == "-h" || a == "--help") usage(0);
+        else if (a == "-V" || a == "--version") { std::printf("raytracer 0.1.0 (MI355X backend, ABI %u.%u)\n", rt_abi_version() >> 16, rt_abi_version() & 0xffff); return 0; }
+        else { std::fprintf(stderr, "error: unexpected argument '%s' found\n", a.c_str()); usage(2); }
+    }
+
+    rt_camera cam;
+    std::vector<rt_hittable> generated;
+    const rt_hittable* hittables = nullptr;
+    const rt_texture* textures = nullptr;
+    size_t n = 0, n_textures = 0;
+    rt_config* cfg = nullptr;
+    if (random_scene) {  // src/main.rs:22-24
+        size_t count = 0;
+        generated.resize(488);
+        if (rt_gen_scene(scene_seed, generated.data(), generated.size(), &count)) die("gen_scene");
+        generated.resize(count);
+        std::printf("number of BoundingBox: %zu\n", count);  // src/scenegen.rs:65
+        if (rt_default_camera(width, height, &cam)) die("default_camera");
+        hittables = generated.data();
+        n = count;
+    } else {  // src/main.rs:25-33
+        if (rt_config_load(scene_path.c_str(), &cfg)) die("scene");
+        if (rt_config_view(cfg, &cam, &hittables, &n, &textures, &n_textures)) die("scene");
+    }
+
+    // src/main.rs:35-42; unlike the reference the file is truncated, so a smaller image leaves no stale tail
+    const int fd = ::open(out_path.c_str(), O_CREAT | O_WRONLY | O_TRUNC, 0644);
+    if (fd < 0) {
+        std::fprintf(stderr, "raytracer: Unable to open file to write: %s: %s\n", out_path.c_str(), std::strerror(errno));
+        return 101;
+    }
+    char header[64];
+    const int hl = std::snprintf(header, sizeof header, "P3\n%u %u\n255\n", cam.horiz_res, cam.vert_res);
+    if (::write(fd, header, size_t(hl)) != hl) {
+        std::fprintf(stderr, "raytracer: Unable to write header to ppm\n");
+        return 101;
+    }
+
+    std::printf("Starting render...\n");
+    std::printf("Computing with %llu samples\n", (unsigned long long)cam.horiz_res * cam.vert_res * spp);  // 64-bit, unlike src/main.rs:48
+    std::fflush(stdout);
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = random_scene
+                       ? rt_accel_render_into_file(fd, &cam, hittables, n, textures, n_textures, spp, depth, seed, device)
+                       : rt_render_into_file(fd, &cam, hittables, n, textures, n_textures, spp, depth, seed, device);
+    if (rc) die("render");
+    ::close(fd);
+    const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::printf("Render finished in %llus\n", (unsigned long long)s);  // src/main.rs:59
+    rt_config_destroy(cfg);
+    return 0;
+}
