@@ -81,7 +81,7 @@ struct RenderParams {
     uint32_t sample_begin, sample_end, depth, flags;
     uint32_t key0, key1;
     uint32_t n_pixels, tiles_x, tiles_y;
-    uint32_t trav_threshold, inner_threshold;  // schedule of render_kernel_ws
+    uint32_t trav_threshold, inner_threshold, leave_threshold;  // schedule of render_kernel_ws
     uint32_t n_chunks, chunk_spp;              // a work item = one 8x8 tile x one chunk of chunk_spp samples
 };
 
@@ -633,6 +633,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(SceneDev S, CamDev C, Re
 // the descent stays conservative), child links as int16, spheres as f64.
 constexpr int kTravThreshold = 12;
 constexpr int kInnerThreshold = 8;
+constexpr int kLeaveThreshold = 20;  // lanes that may leave the inner nodes before the wave turns to the leaves
 
 struct Node16 {       // 32 bytes: two 16-byte LDS reads
     uint16_t h[12];   // lo0.xyz hi0.xyz lo1.xyz hi1.xyz as IEEE half bits
@@ -941,6 +942,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel_ws(SceneDev S, CamDev C, 
     uint32_t next_sample = 0, item_end = 0, chunk = 0, pix_xy = 0;
     float ar = 0.0f, ag = 0.0f, ab = 0.0f;
     const int trav_threshold = int(P.trav_threshold), inner_threshold = int(P.inner_threshold);
+    const int leave_threshold = int(P.leave_threshold);
     const uint32_t q0_addr = lds_address(lds_q0), q1_addr = lds_address(lds_q1), stk_addr = lds_address(stk);
 
     for (;;) {
@@ -1005,7 +1007,10 @@ __global__ __launch_bounds__(BLOCK) void render_kernel_ws(SceneDev S, CamDev C, 
             if (n_desc == 0 || (n_desc < trav_threshold && someone_waits)) break;
             if (STATS) st[7]++;
             if (LDS16 && !STATS) {
-                inner_loop_lds16<BLOCK>(T, q0_addr, q1_addr, stk_addr, inner_threshold);
+                // inner steps until fewer than inner_threshold lanes are on inner nodes, or leave_threshold lanes
+                // have left them (for a leaf or for good) since this run of steps began
+                const int n_inner = int(__popcll(__ballot(T.node >= 0)));
+                inner_loop_lds16<BLOCK>(T, q0_addr, q1_addr, stk_addr, max(inner_threshold, n_inner - leave_threshold));
             } else {
                 for (;;) {
                     const int n_inner = int(__popcll(__ballot(T.node >= 0)));
@@ -1260,7 +1265,9 @@ RenderParams make_params(const rt_camera& cam, const rt_render_opts& o) {
     P.n_chunks = (spp + P.chunk_spp - 1) / P.chunk_spp;
     P.trav_threshold = kTravThreshold;
     P.inner_threshold = kInnerThreshold;
+    P.leave_threshold = kLeaveThreshold;
     if (const char* e = std::getenv("RT_TRAV_THRESHOLD")) P.trav_threshold = uint32_t(std::atoi(e));    // tuning aid
+    if (const char* e = std::getenv("RT_LEAVE_THRESHOLD")) P.leave_threshold = uint32_t(std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("RT_INNER_THRESHOLD")) P.inner_threshold = uint32_t(std::max(1, std::atoi(e)));
     return P;
 }
