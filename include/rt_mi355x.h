@@ -91,6 +91,9 @@ typedef struct rt_scene_info {
     double build_seconds;  /* host BVH build + flatten + upload */
     int32_t device;
     int32_t lds_resident;  /* 1 when nodes and spheres are staged in LDS by the render kernel */
+    uint32_t n_wide;       /* spheres kept out of the BVH because their box covers most of the others (tested once
+                              per segment, like the discs); n_nodes counts the tree over the remaining spheres */
+    uint32_t reserved;
 } rt_scene_info;
 
 /* Sample range and launch options of one render call. */

@@ -73,6 +73,8 @@ class rt_scene_info(C.Structure):
         ("build_seconds", C.c_double),
         ("device", C.c_int32),
         ("lds_resident", C.c_int32),
+        ("n_wide", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 

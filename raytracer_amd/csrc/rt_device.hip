@@ -51,7 +51,7 @@ struct TexImgDev {
 
 struct SceneDev {
     const Node* nodes;
-    const double4* sph;     // leaf order: centre xyz, radius
+    const double4* sph;     // the n_tree spheres of the BVH in leaf order, then the n_wide spheres kept out of it
     const DiscDev* discs;   // scene order
     const float4* mat;      // spheres in leaf order, then discs: albedo rgb + (fuzz | refractive index)
     const int32_t* kind;    // same indexing: material kind | texmat index << 8
@@ -59,6 +59,8 @@ struct SceneDev {
     const TexMatDev* texmat;
     const TexImgDev* teximg;
     int32_t n_nodes, n_spheres, n_discs;
+    int32_t n_tree, n_wide; // n_spheres = n_tree + n_wide; a wide sphere's box covers most of the others, so every
+                            // ray would reach its leaf anyway: it is tested once per segment before the descent
     float eps;              // origin widening for the f32 descent
 };
 
@@ -206,9 +208,17 @@ __device__ __forceinline__ Best closest_hit(const SceneDev& S, double ox, double
         double t;
         if (disc_intersect_f64(S.discs[i], ox, oy, oz, dx, dy, dz, &t)) consider(best, t, S.n_spheres + i, S.prim_id[S.n_spheres + i]);
     }
-    if (S.n_nodes == 0) return best;
     // a sphere parameter is always positive: nothing can beat a non-positive disc hit
     if (best.k >= 0 && best.t <= 0.0) return best;
+    for (int32_t i = 0; i < S.n_wide; ++i) {
+        const int32_t k = S.n_tree + i;
+        const double4 s = S.sph[k];
+        double t;
+        bool ok = true;
+        if (GATE) ok = own_box_line_test_f64(s.x, s.y, s.z, s.w, ox, oy, oz, dx, dy, dz);
+        if (ok && sphere_intersect_f64(s.x, s.y, s.z, s.w, ox, oy, oz, dx, dy, dz, &t)) consider(best, t, k, S.prim_id[k]);
+    }
+    if (S.n_nodes == 0) return best;
 
     const float of[3] = {float(ox), float(oy), float(oz)};
     const float df[3] = {dxf, dyf, dzf};
@@ -632,6 +642,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(SceneDev S, CamDev C, Re
 // With LDS16 the whole scene is staged in LDS: boxes as f16 (rounded outward, so
 // the descent stays conservative), child links as int16, spheres as f64.
 constexpr int kTravThreshold = 12;
+constexpr int kMaxWide = 4;         // spheres kept out of the tree at most (tested linearly per segment)
 constexpr int kInnerThreshold = 8;
 constexpr int kLeaveThreshold = 20;  // lanes that may leave the inner nodes before the wave turns to the leaves
 
@@ -653,7 +664,33 @@ struct Trav {
     Best best;
 };
 
-__device__ __forceinline__ void trav_begin(const SceneDev& S, const Path& p, Trav& T) {
+// sphere_intersect_f64 followed by consider(), with selects instead of branches: the same operations in the same
+// order (a negative discriminant gives a NaN root, which fails both comparisons).  Returns whether `best` changed.
+__device__ __forceinline__ bool sphere_candidate(const double4 s, int32_t k, int32_t id, const Path& p, bool enabled,
+                                                 Best& best) {
+    bool better;
+    double t;
+    {
+#pragma clang fp contract(off)
+        const double rx = p.ox - s.x, ry = p.oy - s.y, rz = p.oz - s.z;
+        const double b = 2.0 * (rx * p.dx + ry * p.dy + rz * p.dz);
+        const double c = (rx * rx + ry * ry + rz * rz) - s.w * s.w;
+        const double discrm = b * b - 4.0 * c;
+        const double sq = __dsqrt_rn(discrm);
+        const double t_smaller = -0.5 * (b + sq);
+        const double t_larger = t_smaller + sq;
+        const bool near_ok = t_smaller > 0.0;
+        const bool hit = !(discrm < 0.0) && (near_ok || t_larger > 1.0e-6);
+        t = near_ok ? t_smaller : t_larger;
+        better = enabled && hit && (best.k < 0 || t < best.t || (t == best.t && id < best.id));
+    }
+    best.t = better ? t : best.t;
+    best.k = better ? k : best.k;
+    best.id = better ? id : best.id;
+    return better;
+}
+
+__device__ __forceinline__ void trav_begin(const SceneDev& S, const Tables& Tb, const Path& p, Trav& T) {
     T.best.t = 0.0;
     T.best.k = -1;
     T.best.id = 0x7fffffff;
@@ -664,8 +701,13 @@ __device__ __forceinline__ void trav_begin(const SceneDev& S, const Path& p, Tra
         if (disc_intersect_f64(S.discs[i], p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, &t))
             consider(T.best, t, S.n_spheres + i, S.prim_id[S.n_spheres + i]);
     }
-    const bool skip = (S.n_nodes == 0) || (T.best.k >= 0 && T.best.t <= 0.0);
-    T.node = skip ? kLeafSentinel : 0;
+    // a sphere parameter is always positive: nothing can beat a non-positive disc hit
+    const bool spheres_matter = !(T.best.k >= 0 && T.best.t <= 0.0);
+    for (int32_t i = 0; i < S.n_wide; ++i) {
+        const int32_t k = S.n_tree + i;
+        sphere_candidate(Tb.sph[k], k, Tb.prim_id[k], p, spheres_matter, T.best);
+    }
+    T.node = (S.n_nodes == 0 || !spheres_matter) ? kLeafSentinel : 0;
     const float of[3] = {float(p.ox), float(p.oy), float(p.oz)};
     const float df[3] = {float(p.dx), float(p.dy), float(p.dz)};
 #pragma unroll
@@ -857,30 +899,8 @@ __device__ __forceinline__ void inner_loop_lds16(Trav& T, uint32_t q0_addr, uint
 template <bool LDS16, int BLOCK>
 __device__ __forceinline__ void leaf_step(const Tables& Tb, const Path& p, Trav& T, int32_t* stk) {
     const int32_t k = ~T.node;
-    const double4 s = Tb.sph[k];
-    const int32_t id = Tb.prim_id[k];
-    // sphere_intersect_f64 and consider() with selects instead of branches: the same operations in the same
-    // order (a negative discriminant gives a NaN root, which fails both comparisons below)
-    bool better;
-    double t;
-    {
-#pragma clang fp contract(off)
-        const double rx = p.ox - s.x, ry = p.oy - s.y, rz = p.oz - s.z;
-        const double b = 2.0 * (rx * p.dx + ry * p.dy + rz * p.dz);
-        const double c = (rx * rx + ry * ry + rz * rz) - s.w * s.w;
-        const double discrm = b * b - 4.0 * c;
-        const double sq = __dsqrt_rn(discrm);
-        const double t_smaller = -0.5 * (b + sq);
-        const double t_larger = t_smaller + sq;
-        const bool near_ok = t_smaller > 0.0;
-        const bool hit = !(discrm < 0.0) && (near_ok || t_larger > 1.0e-6);
-        t = near_ok ? t_smaller : t_larger;
-        better = hit && (T.best.k < 0 || t < T.best.t || (t == T.best.t && id < T.best.id));
-    }
-    T.best.t = better ? t : T.best.t;
-    T.best.k = better ? k : T.best.k;
-    T.best.id = better ? id : T.best.id;
-    T.tmax = better ? float(t) * (1.0f + 4.0e-7f) : T.tmax;
+    const bool better = sphere_candidate(Tb.sph[k], k, Tb.prim_id[k], p, true, T.best);
+    T.tmax = better ? float(T.best.t) * (1.0f + 4.0e-7f) : T.tmax;
     pop<BLOCK>(T, stk);
 }
 
@@ -994,7 +1014,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel_ws(SceneDev S, CamDev C, 
                 } else if (!scatter_part(P, p, sf, r)) {
                     alive = false;  // bounded fuzz loop gave up: the path contributes nothing
                 }
-                if (alive) trav_begin(S, p, T);
+                if (alive) trav_begin(S, Tb, p, T);
             }
         }
         if (__all(done)) break;
@@ -1006,15 +1026,16 @@ __global__ __launch_bounds__(BLOCK) void render_kernel_ws(SceneDev S, CamDev C, 
             const bool someone_waits = __any(!descending && !done);
             if (n_desc == 0 || (n_desc < trav_threshold && someone_waits)) break;
             if (STATS) st[7]++;
+            // inner steps until fewer than inner_threshold lanes are on inner nodes, or leave_threshold lanes have
+            // left them (for a leaf or for good) since this run of steps began; a run never ends while lanes are on
+            // inner nodes and none waits at a leaf
+            const int run_threshold = max(inner_threshold, int(__popcll(__ballot(T.node >= 0))) - leave_threshold);
             if (LDS16 && !STATS) {
-                // inner steps until fewer than inner_threshold lanes are on inner nodes, or leave_threshold lanes
-                // have left them (for a leaf or for good) since this run of steps began
-                const int n_inner = int(__popcll(__ballot(T.node >= 0)));
-                inner_loop_lds16<BLOCK>(T, q0_addr, q1_addr, stk_addr, max(inner_threshold, n_inner - leave_threshold));
+                inner_loop_lds16<BLOCK>(T, q0_addr, q1_addr, stk_addr, run_threshold);
             } else {
                 for (;;) {
                     const int n_inner = int(__popcll(__ballot(T.node >= 0)));
-                    if (n_inner < inner_threshold && (n_inner == 0 || __any(T.node < 0 && T.node != kLeafSentinel))) break;
+                    if (n_inner < run_threshold && (n_inner == 0 || __any(T.node < 0 && T.node != kLeafSentinel))) break;
                     if (STATS) { st[0]++; if (T.node >= 0) st[1]++; }
                     if (T.node >= 0) inner_step<LDS16, BLOCK>(S, lds_q0, lds_q1, T, stk);
                 }
@@ -1335,16 +1356,55 @@ int rt_scene_create(const rt_hittable* hittables, size_t n_hittables, const rt_t
         return bail(fail(RT_ERR_DEVICE, "rt_scene_create: device %d is %s, this library is built for gfx950 only", device, prop.gcnArchName));
     sc->n_cu = prop.multiProcessorCount;
 
-    // BVH over the spheres
-    std::vector<double> sph4(4 * sphere_ids.size());
-    for (size_t i = 0; i < sphere_ids.size(); ++i) {
-        const rt_hittable& h = hittables[sphere_ids[i]];
+    // Wide spheres: a sphere whose box covers at least half of the box around all the others (the ground sphere of
+    // src/scenegen.rs:18-21 is the example) would be reached by nearly every ray whatever the tree looks like, and
+    // its huge box would sit in the root.  Up to kMaxWide of them stay out of the tree and are tested once per
+    // segment before the descent.  The result of a segment does not depend on this choice.
+    std::vector<uint32_t> tree_ids = sphere_ids, wide_ids;
+    auto box_of = [&](uint32_t id, double lo[3], double hi[3]) {
+        const rt_hittable& h = hittables[id];
+        for (int a = 0; a < 3; ++a) { lo[a] = h.centre[a] - std::fabs(h.radius); hi[a] = h.centre[a] + std::fabs(h.radius); }
+    };
+    auto half_area = [](const double lo[3], const double hi[3]) {
+        const double x = std::max(hi[0] - lo[0], 0.0), y = std::max(hi[1] - lo[1], 0.0), z = std::max(hi[2] - lo[2], 0.0);
+        return x * y + y * z + z * x;
+    };
+    while (wide_ids.size() < size_t(kMaxWide) && tree_ids.size() >= 2) {
+        size_t big = 0;
+        double big_area = -1.0;
+        for (size_t i = 0; i < tree_ids.size(); ++i) {
+            double lo[3], hi[3];
+            box_of(tree_ids[i], lo, hi);
+            const double area = half_area(lo, hi);
+            if (area > big_area) { big_area = area; big = i; }
+        }
+        double ulo[3] = {1e300, 1e300, 1e300}, uhi[3] = {-1e300, -1e300, -1e300};
+        for (size_t i = 0; i < tree_ids.size(); ++i) {
+            if (i == big) continue;
+            double lo[3], hi[3];
+            box_of(tree_ids[i], lo, hi);
+            for (int a = 0; a < 3; ++a) { ulo[a] = std::min(ulo[a], lo[a]); uhi[a] = std::max(uhi[a], hi[a]); }
+        }
+        double blo[3], bhi[3], ilo[3], ihi[3];
+        box_of(tree_ids[big], blo, bhi);
+        for (int a = 0; a < 3; ++a) { ilo[a] = std::max(blo[a], ulo[a]); ihi[a] = std::min(bhi[a], uhi[a]); }
+        const bool overlaps = ilo[0] <= ihi[0] && ilo[1] <= ihi[1] && ilo[2] <= ihi[2];
+        if (!overlaps || !(half_area(ilo, ihi) >= 0.5 * half_area(ulo, uhi))) break;
+        wide_ids.push_back(tree_ids[big]);
+        tree_ids.erase(tree_ids.begin() + long(big));
+    }
+    std::sort(wide_ids.begin(), wide_ids.end());
+
+    // BVH over the other spheres
+    std::vector<double> sph4(4 * tree_ids.size());
+    for (size_t i = 0; i < tree_ids.size(); ++i) {
+        const rt_hittable& h = hittables[tree_ids[i]];
         sph4[4 * i] = h.centre[0]; sph4[4 * i + 1] = h.centre[1]; sph4[4 * i + 2] = h.centre[2]; sph4[4 * i + 3] = h.radius;
     }
     uint32_t lg = 0;
-    while ((size_t(1) << lg) < sphere_ids.size()) ++lg;
+    while ((size_t(1) << lg) < tree_ids.size()) ++lg;
     BuiltBvh bvh;
-    build_bvh(sph4.data(), sphere_ids.size(), lg + 7, &bvh);
+    build_bvh(sph4.data(), tree_ids.size(), lg + 7, &bvh);
     sc->stack_depth = bvh.depth + 2;  // one pending entry per level, plus slot 0 (the sentinel below every stack)
     double bound = 0.0;
     for (int a = 0; a < 3; ++a) bound = std::max(bound, std::max(std::fabs(bvh.scene_lo[a]), std::fabs(bvh.scene_hi[a])));
@@ -1378,8 +1438,9 @@ int rt_scene_create(const rt_hittable* hittables, size_t n_hittables, const rt_t
         h_kind[k] = word;
         h_id[k] = int32_t(id);
     };
+    const size_t n_tree = tree_ids.size(), n_wide = wide_ids.size();
     for (size_t k = 0; k < n_s; ++k) {
-        const uint32_t id = sphere_ids[bvh.leaf_order[k]];
+        const uint32_t id = k < n_tree ? tree_ids[bvh.leaf_order[k]] : wide_ids[k - n_tree];
         const rt_hittable& h = hittables[id];
         h_sph[k] = make_double4(h.centre[0], h.centre[1], h.centre[2], h.radius);
         fill_material(k, id);
@@ -1440,6 +1501,8 @@ int rt_scene_create(const rt_hittable* hittables, size_t n_hittables, const rt_t
     if ((rc = upload(sc, h_teximg, &sc->dev.teximg)) != RT_OK) return bail(rc);
     sc->dev.n_nodes = int32_t(bvh.nodes.size());
     sc->dev.n_spheres = int32_t(n_s);
+    sc->dev.n_tree = int32_t(n_tree);
+    sc->dev.n_wide = int32_t(n_wide);
     sc->dev.n_discs = int32_t(n_d);
     sc->dev.eps = 0.0f;
     {
@@ -1459,6 +1522,8 @@ int rt_scene_create(const rt_hittable* hittables, size_t n_hittables, const rt_t
     sc->info.stack_depth = sc->stack_depth;
     sc->info.device = device;
     sc->info.lds_resident = sc->d_nodes16 ? 1 : 0;
+    sc->info.n_wide = uint32_t(n_wide);
+    sc->info.reserved = 0;
     sc->info.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     *out = sc;
     return RT_OK;

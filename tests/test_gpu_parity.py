@@ -39,7 +39,8 @@ def _check_hits(ids, t, nrm, want_ids, want_t, want_n):
 def test_scene_info(scene1):
     i = scene1.info
     assert i["n_hittables"] == 488 and i["n_spheres"] == 488 and i["n_discs"] == 0
-    assert i["n_nodes"] == 487  # one sphere per leaf: N-1 inner nodes
+    assert i["n_wide"] == 1  # the ground sphere covers all the others: tested per segment, outside the tree
+    assert i["n_nodes"] == 486  # one sphere per leaf: N-1 inner nodes over the other 487
     assert 9 <= i["bvh_depth"] <= 16 and i["stack_depth"] == i["bvh_depth"] + 2
 
 
@@ -369,7 +370,7 @@ def test_million_sphere_scene_primary_hits_and_render(rt, ob):
     assert len(h) == 1000001
     scene = rt.Scene(h)
     info = scene.info
-    assert info["n_nodes"] == 1000000 and info["lds_resident"] == 0 and info["bvh_depth"] <= 27
+    assert info["n_wide"] == 1 and info["n_nodes"] == 999999 and info["lds_resident"] == 0 and info["bvh_depth"] <= 27
     cam = rt.Camera.build([0, 0, 0], [130, 40, 30], 1.0, 0.1, 1920, 1080)
     rng = np.random.default_rng(1)
     px = rng.choice(1920 * 1080, 384, replace=False)
