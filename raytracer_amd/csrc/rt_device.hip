@@ -640,7 +640,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(SceneDev S, CamDev C, Re
 //   * the shade phase scatters / terminates / regenerates all waiting lanes at
 //     once and sends them back into the descent.
 // With LDS16 the whole scene is staged in LDS: boxes as f16 (rounded outward, so
-// the descent stays conservative), child links as int16, spheres as f64.
+// the descent stays conservative), child links as int32, spheres as f64.
 constexpr int kTravThreshold = 12;
 constexpr int kMaxWide = 4;         // spheres kept out of the tree at most (tested linearly per segment)
 constexpr int kInnerThreshold = 8;
@@ -648,8 +648,7 @@ constexpr int kLeaveThreshold = 20;  // lanes that may leave the inner nodes bef
 
 struct Node16 {       // 32 bytes: two 16-byte LDS reads
     uint16_t h[12];   // lo0.xyz hi0.xyz lo1.xyz hi1.xyz as IEEE half bits
-    int16_t child0, child1;
-    uint32_t pad;
+    int32_t child0, child1;
 };
 static_assert(sizeof(Node16) == 32, "Node16 must be 32 bytes");
 
@@ -775,8 +774,8 @@ __device__ __forceinline__ void inner_step(const SceneDev& S, const uint4* lds_q
         // h0 = lo0.xy  h1 = lo0.z hi0.x  h2 = hi0.yz  h3 = lo1.xy  h4 = lo1.z hi1.x  h5 = hi1.yz
         slab2(T, float(h0.x), float(h0.y), float(h1.x), float(h1.y), float(h2.x), float(h2.y), float(h3.x), float(h3.y),
               float(h4.x), float(h4.y), float(h5.x), float(h5.y), &en0, &ex0, &en1, &ex1);
-        c0 = int32_t(int16_t(b.z & 0xffffu));
-        c1 = int32_t(b.z) >> 16;
+        c0 = int32_t(b.z);
+        c1 = int32_t(b.w);
     } else {
         const float4* q = reinterpret_cast<const float4*>(S.nodes + T.node);
         const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
@@ -858,20 +857,18 @@ __device__ __forceinline__ void inner_loop_lds16(Trav& T, uint32_t q0_addr, uint
         "v_max_f32_e32 v115, 0, v115\n\t"
         "v_min_f32_e32 v116, v116, %[tmax]\n\t"
         "v_max3_f32 v122, v122, v113, v115\n\t"   // entry parameter of child 1
-        "v_min3_f32 v127, v112, v114, v116\n\t"   // exit parameter of child 1
-        // v126 = child links: c0 in the low half, c1 in the high half, both signed
-        "v_bfe_i32 v120, v126, 0, 16\n\t"
-        "v_ashrrev_i32_e32 v121, 16, v126\n\t"
+        "v_min3_f32 v120, v112, v114, v116\n\t"   // exit parameter of child 1
+        // v126, v127 = child links c0, c1
         "v_cmp_le_f32_e64 s[90:91], v118, v119\n\t"   // h0
-        "v_cmp_le_f32_e64 s[92:93], v122, v127\n\t"   // h1
+        "v_cmp_le_f32_e64 s[92:93], v122, v120\n\t"   // h1
         "v_cmp_lt_f32_e64 s[94:95], v122, v118\n\t"   // child 1 is entered first
         "s_and_b64 s[96:97], s[90:91], s[92:93]\n\t"  // both
         "s_or_b64 s[98:99], s[90:91], s[92:93]\n\t"   // any
         "s_and_b64 s[94:95], s[94:95], s[92:93]\n\t"
         "s_andn2_b64 s[94:95], s[90:91], s[94:95]\n\t"  // go to c0: h0 and not (h1 and child 1 first)
         "s_andn2_b64 s[98:99], exec, s[98:99]\n\t"      // none
-        "v_cndmask_b32_e64 %[node], v121, v120, s[94:95]\n\t"
-        "v_cndmask_b32_e64 v112, v120, v121, s[94:95]\n\t"  // the other child, pushed where both are hit
+        "v_cndmask_b32_e64 %[node], v127, v126, s[94:95]\n\t"
+        "v_cndmask_b32_e64 v112, v126, v127, s[94:95]\n\t"  // the other child, pushed where both are hit
         "s_mov_b64 exec, s[96:97]\n\t"
         "v_lshl_add_u32 v113, %[sp], %[shift], %[stk]\n\t"
         "ds_write_b32 v113, %[top]\n\t"
@@ -1471,12 +1468,12 @@ int rt_scene_create(const rt_hittable* hittables, size_t n_hittables, const rt_t
     }
 
     int rc;
-    // f16 copy of the nodes for the LDS-resident kernel: small scenes only (int16 child links, LDS capacity)
+    // f16 copy of the nodes for the LDS-resident kernel: scenes that leave room for two workgroups per CU
     {
         const size_t n_prims = n_s + n_d;
         const size_t scene_bytes = 32 * bvh.nodes.size() + 32 * n_s + 16 * n_prims + 2 * 16 * ((n_prims + 3) / 4);
         const size_t with_stack = scene_bytes + size_t(sc->stack_depth) * 512 * sizeof(int32_t);
-        if (n_s > 0 && n_s <= 32767 && bvh.nodes.size() <= 32767 && with_stack <= 80 * 1024) {
+        if (n_s > 0 && with_stack <= 80 * 1024) {
             std::vector<Node16> n16(bvh.nodes.size());
             for (size_t i = 0; i < bvh.nodes.size(); ++i) {
                 const Node& nd = bvh.nodes[i];
@@ -1484,8 +1481,7 @@ int rt_scene_create(const rt_hittable* hittables, size_t n_hittables, const rt_t
                     n16[i].h[a] = half_round_down(nd.lo0[a]); n16[i].h[3 + a] = half_round_up(nd.hi0[a]);
                     n16[i].h[6 + a] = half_round_down(nd.lo1[a]); n16[i].h[9 + a] = half_round_up(nd.hi1[a]);
                 }
-                n16[i].child0 = int16_t(nd.child0); n16[i].child1 = int16_t(nd.child1);
-                n16[i].pad = 0;
+                n16[i].child0 = nd.child0; n16[i].child1 = nd.child1;
             }
             if ((rc = upload(sc, n16, &sc->d_nodes16)) != RT_OK) return bail(rc);
             sc->lds16_scene_bytes = scene_bytes;
