@@ -148,6 +148,18 @@ int rt_gen_scene_shells(uint32_t shells, rt_hittable* out, size_t cap, size_t* n
  * Discs are kept outside the BVH and tested one by one, as src/lib.rs:46-49 does. */
 int rt_scene_create(const rt_hittable* hittables, size_t n_hittables, const rt_texture* textures, size_t n_textures,
                     int device, rt_scene** out);
+
+/* The same with a choice of tree builder.  Both replace make_coveringtree (src/boundingvolume.rs:192-208) and
+ * give the same nearest hits; they differ in build time and in how many boxes a ray visits.
+ *   RT_BUILDER_SAH_HOST     binned surface-area heuristic on the host (default; 1 M spheres: ~0.9 s)
+ *   RT_BUILDER_LBVH_DEVICE  Morton-order linear BVH built on the GPU (1 M spheres: milliseconds) */
+enum rt_builder { RT_BUILDER_DEFAULT = 0, RT_BUILDER_SAH_HOST = 1, RT_BUILDER_LBVH_DEVICE = 2 };
+typedef struct rt_scene_opts {
+    uint32_t builder; /* rt_builder */
+    uint32_t reserved[7];
+} rt_scene_opts;
+int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const rt_texture* textures,
+                       size_t n_textures, int device, const rt_scene_opts* opts, rt_scene** out);
 void rt_scene_destroy(rt_scene* scene);
 int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out);
 

@@ -78,6 +78,13 @@ class rt_scene_info(C.Structure):
     ]
 
 
+class rt_scene_opts(C.Structure):
+    _fields_ = [("builder", C.c_uint32), ("reserved", C.c_uint32 * 7)]
+
+
+RT_BUILDER_DEFAULT, RT_BUILDER_SAH_HOST, RT_BUILDER_LBVH_DEVICE = 0, 1, 2
+
+
 class rt_render_opts(C.Structure):
     _fields_ = [
         ("sample_begin", C.c_uint32),
@@ -104,6 +111,7 @@ PROTOTYPES = {
     "rt_gen_scene_grid": (_i, [_u64, _u32, _vp, _sz, C.POINTER(_sz)]),
     "rt_gen_scene_shells": (_i, [_u32, _vp, _sz, C.POINTER(_sz)]),
     "rt_scene_create": (_i, [_vp, _sz, C.POINTER(rt_texture), _sz, _i, C.POINTER(_vp)]),
+    "rt_scene_create_ex": (_i, [_vp, _sz, C.POINTER(rt_texture), _sz, _i, _vp, C.POINTER(_vp)]),
     "rt_scene_destroy": (None, [_vp]),
     "rt_scene_get_info": (_i, [_vp, C.POINTER(rt_scene_info)]),
     "rt_render_device": (_i, [_vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts), _vp, _vp]),

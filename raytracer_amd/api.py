@@ -127,7 +127,8 @@ def hittables(items):
 class Scene:
     """Owner of an rt_scene handle (Box<[Hittable]> / Box<CoveringTree>, src/main.rs:10-13)."""
 
-    def __init__(self, hittable_array, textures=(), device=0):
+    def __init__(self, hittable_array, textures=(), device=0, builder="sah"):
+        """builder: "sah" (host, binned surface-area heuristic) or "lbvh" (built on the GPU from Morton codes)."""
         h = np.ascontiguousarray(hittable_array, dtype=HITTABLE_DTYPE)
         self.hittables = h
         self._tex_keep = [np.ascontiguousarray(t, dtype=np.uint8) for t in textures]
@@ -140,7 +141,10 @@ class Scene:
             tex[i].width = t.shape[1]
             tex[i].height = t.shape[0]
         handle = C.c_void_p(None)
-        check(lib.rt_scene_create(ptr(h) if len(h) else None, len(h), tex, len(self._tex_keep), int(device), C.byref(handle)))
+        so = _abi.rt_scene_opts()
+        so.builder = {"sah": _abi.RT_BUILDER_SAH_HOST, "lbvh": _abi.RT_BUILDER_LBVH_DEVICE}[builder]
+        check(lib.rt_scene_create_ex(ptr(h) if len(h) else None, len(h), tex, len(self._tex_keep), int(device), C.byref(so),
+                                     C.byref(handle)))
         self.handle = handle
         self.device = device
 

@@ -1316,7 +1316,14 @@ void rt_scene_destroy(rt_scene* scene) {
 
 int rt_scene_create(const rt_hittable* hittables, size_t n_hittables, const rt_texture* textures, size_t n_textures,
                     int device, rt_scene** out) {
+    return rt_scene_create_ex(hittables, n_hittables, textures, n_textures, device, nullptr, out);
+}
+
+int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const rt_texture* textures, size_t n_textures,
+                       int device, const rt_scene_opts* scene_opts, rt_scene** out) {
     if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: null out pointer");
+    const uint32_t builder = scene_opts ? scene_opts->builder : uint32_t(RT_BUILDER_DEFAULT);
+    if (builder > RT_BUILDER_LBVH_DEVICE) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create_ex: unknown builder %u", builder);
     *out = nullptr;
     if (!hittables && n_hittables) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: null hittables");
     if (!textures && n_textures) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: null textures");
@@ -1401,7 +1408,11 @@ int rt_scene_create(const rt_hittable* hittables, size_t n_hittables, const rt_t
     uint32_t lg = 0;
     while ((size_t(1) << lg) < tree_ids.size()) ++lg;
     BuiltBvh bvh;
-    build_bvh(sph4.data(), tree_ids.size(), lg + 7, &bvh);
+    if (builder == RT_BUILDER_LBVH_DEVICE) {
+        if (int brc = build_lbvh_device(sph4.data(), tree_ids.size(), &bvh)) return bail(brc);
+    } else {
+        build_bvh(sph4.data(), tree_ids.size(), lg + 7, &bvh);
+    }
     sc->stack_depth = bvh.depth + 2;  // one pending entry per level, plus slot 0 (the sentinel below every stack)
     double bound = 0.0;
     for (int a = 0; a < 3; ++a) bound = std::max(bound, std::max(std::fabs(bvh.scene_lo[a]), std::fabs(bvh.scene_hi[a])));

@@ -36,6 +36,10 @@ struct BuiltBvh {
 // bounds the inner-node levels (and with it the traversal stack).
 void build_bvh(const double* spheres, size_t n, uint32_t max_depth, BuiltBvh* out);
 
+// The same contract, built on the current HIP device: Morton codes, radix sort, one thread per inner node
+// for the topology, one thread per leaf for the boxes (rt_lbvh.hip).  Returns an rt_status.
+int build_lbvh_device(const double* spheres, size_t n, BuiltBvh* out);
+
 // SplitMix64 used by the seeded scene generators.
 struct SplitMix64 {
     uint64_t state;

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--builder", default="sah", choices=["sah", "lbvh"])
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -49,7 +50,7 @@ def main():
         raise SystemExit("unknown config")
     gen_s = time.time() - t0
     spp = a.spp or spp
-    scene = rt.Scene(h, tex)
+    scene = rt.Scene(h, tex, builder=a.builder)
     info = scene.info
     H, W = cam.vert_res, cam.horiz_res
     d_sum = torch.zeros(H, W, 3, dtype=torch.float32, device="cuda")
@@ -65,7 +66,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms.append(e0.elapsed_time(e1))
-    out = {"config": a.config, "n_hittables": int(info["n_hittables"]), "bvh_nodes": int(info["n_nodes"]), "bvh_depth": int(info["bvh_depth"]),
+    out = {"config": a.config, "builder": a.builder, "n_hittables": int(info["n_hittables"]), "bvh_nodes": int(info["n_nodes"]), "bvh_depth": int(info["bvh_depth"]),
            "lds_resident": int(info["lds_resident"]), "scene_device_MB": round(info["device_bytes"] / 1e6, 2),
            "scene_build_s": round(info["build_seconds"], 3), "scene_gen_s": round(gen_s, 3), "width": W, "height": H, "spp": spp, "depth": depth,
            "kernel_ms": round(min(ms), 3), "Mpaths_per_s": round(W * H * spp / min(ms) / 1e3, 1),

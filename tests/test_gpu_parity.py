@@ -425,3 +425,61 @@ def test_argument_errors(scene1, rt):
     with pytest.raises(rt.RtError) as e:
         rt.Scene(bad)
     assert e.value.status == 2
+
+
+def test_lbvh_builder_same_hits_same_image(rt, ob, scene1):
+    """The tree built on the GPU (Morton order) is another conservative tree: every nearest hit, hence every
+    path and the whole image, is identical to the host-built SAH tree's."""
+    h = rt.gen_scene(1)
+    lb = rt.Scene(h, builder="lbvh")
+    info = lb.info
+    assert info["n_wide"] == 1 and info["n_nodes"] == 486 and info["lds_resident"] == 1
+    assert 9 <= info["bvh_depth"] <= 40 and info["stack_depth"] == info["bvh_depth"] + 2
+    g = golden("primary_rays_seed1.npz")
+    ids, t, nrm = lb.trace_primary(g["orig"], g["dir"])
+    assert np.array_equal(ids, g["id"])
+    ids0, t0, nrm0 = scene1.trace_primary(g["orig"], g["dir"])
+    assert np.array_equal(t, t0) and np.array_equal(nrm, nrm0)
+    cam_small = rt.default_camera(160, 96)
+    a, qa = lb.render(cam_small, 6, depth=50, seed=3)
+    b, qb = scene1.render(cam_small, 6, depth=50, seed=3)
+    assert np.array_equal(a, b) and np.array_equal(qa, qb)
+
+
+def test_lbvh_builder_degenerate_inputs(rt, ob):
+    rng = np.random.default_rng(5)
+    cases = {
+        "two": [rt.sphere([0, 0, 0], 1.0, rt.diffuse([.5, .5, .5])), rt.sphere([3, 0, 0], 1.0, rt.diffuse([.5, .5, .5]))],
+        "three_in_a_row": [rt.sphere([float(i) * 2.5, 0, 0], 1.0, rt.diffuse([.5, .5, .5])) for i in range(3)],
+        # equal centres give equal Morton codes: the position in the sorted order splits them
+        "coincident": [rt.sphere([1, 2, 3], 0.5 + 0.1 * i, rt.diffuse([.5, .5, .5])) for i in range(9)],
+        "clustered": [rt.sphere(list(rng.normal(0, 1e-4, 3) + (i % 3) * 5.0), 0.3, rt.diffuse([.5, .5, .5])) for i in range(40)],
+    }
+    for name, items in cases.items():
+        h = rt.hittables(items)
+        o = rng.uniform(-8, 12, (4000, 3)).astype(np.float32)
+        aim = h["centre"][rng.integers(0, len(h), 4000)] + rng.normal(0, 0.4, (4000, 3))  # towards some sphere, roughly
+        d = aim - o; d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        ids, t, nrm = rt.Scene(h, builder="lbvh").trace_primary(o, d)
+        want_ids, want_t, want_n, _ = ob.Scene(h).trace(o, d, ob.TRAVERSE_GATED_BRUTE)
+        assert (want_ids >= 0).sum() > 500, name
+        _check_hits(ids, t, nrm, want_ids, want_t, want_n)
+
+
+def test_lbvh_builder_million_spheres(rt):
+    h = rt.gen_scene_grid(1, 1000)
+    sah, lb = rt.Scene(h), rt.Scene(h, builder="lbvh")
+    assert lb.info["n_nodes"] == 999999 and lb.info["n_wide"] == 1 and lb.info["bvh_depth"] <= 64
+    assert lb.info["build_seconds"] < sah.info["build_seconds"]
+    cam = rt.Camera.build([0, 0, 0], [130, 40, 30], 1.0, 0.1, 1920, 1080)
+    rng = np.random.default_rng(2)
+    px = rng.choice(1920 * 1080, 4096, replace=False)
+    o, d = zip(*[lb.generate_primary(cam, 0, int(p), int(p) + 1) for p in px[:512]])
+    o, d = np.concatenate(o), np.concatenate(d)
+    a, b = lb.trace_primary(o, d), sah.trace_primary(o, d)
+    assert (a[0] > 0).sum() > 100
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    ra, _ = lb.render(cam, 1, depth=50, seed=0, want_rgb8=False)
+    rb, _ = sah.render(cam, 1, depth=50, seed=0, want_rgb8=False)
+    assert np.array_equal(ra, rb)
