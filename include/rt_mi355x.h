@@ -185,8 +185,13 @@ int rt_render_chunk(const rt_camera* cam, const rt_render_opts* opts, uint32_t* 
 int rt_finalize_device(const rt_scene* scene, const float* d_sum_rgb, size_t n_pixels, uint32_t spp_total,
                        uint8_t* d_rgb8, void* stream);
 
+/* The same on host arrays, without a device (used when a finished checkpoint only has to become an image). */
+int rt_finalize(const float* sum_rgb, size_t n_pixels, uint32_t spp_total, uint8_t* rgb8);
+
 /* Host-buffer convenience over the two calls above: sum_rgb (optional) and rgb8
- * (optional) are HOST arrays of horiz_res*vert_res*3; synchronous. */
+ * (optional) are HOST arrays of horiz_res*vert_res*3; synchronous.  With
+ * RT_RENDER_ACCUMULATE sum_rgb is read first and taken to hold samples
+ * [0, sample_begin) of every pixel; rgb8 is then the image of all sample_end samples. */
 int rt_render(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, float* sum_rgb, uint8_t* rgb8);
 
 /* Nearest hit of n rays: what tree_filter + min_by produce for one segment
@@ -260,6 +265,25 @@ int rt_render_into_file(int fd, const rt_camera* cam, const rt_hittable* hittabl
 int rt_accel_render_into_file(int fd, const rt_camera* cam, const rt_hittable* hittables, size_t n_hittables,
                               const rt_texture* textures, size_t n_textures, uint32_t spp, uint32_t depth, uint64_t seed,
                               int device);
+
+/* Progressive renders.  The reference renders all samples in one go and keeps nothing (src/lib.rs:137-157); with
+ * the counter-based sampler a render can stop after any sample index and continue later: a checkpoint file holds
+ * the running per-pixel sums (what rt_render leaves in sum_rgb) and what produced them.  Continuing with
+ * RT_RENDER_ACCUMULATE from samples_done gives the image of an uninterrupted render (bit for bit when both use
+ * the same rt_render_opts.samples_per_item and samples_done is a multiple of it, else to f32 rounding).
+ * `tag` is the caller's to choose (the CLI stores a hash of camera and hittables) and is returned by the load.
+ * rt_checkpoint_load with sum_rgb == NULL reads the header only; capacity counts floats. */
+typedef struct rt_checkpoint_info {
+    uint32_t width, height;
+    uint32_t samples_done; /* the sums hold samples [0, samples_done) */
+    uint32_t depth;
+    uint64_t seed;
+    uint64_t tag;
+} rt_checkpoint_info;
+int rt_checkpoint_save(const char* path, const rt_checkpoint_info* info, const float* sum_rgb);
+int rt_checkpoint_load(const char* path, rt_checkpoint_info* info, float* sum_rgb, size_t capacity);
+/* FNV-1a over a byte range, chained through `basis` (0 = start): a convenient `tag`. */
+uint64_t rt_hash_bytes(const void* bytes, size_t len, uint64_t basis);
 
 #ifdef __cplusplus
 }

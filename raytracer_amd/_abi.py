@@ -78,6 +78,11 @@ class rt_scene_info(C.Structure):
     ]
 
 
+class rt_checkpoint_info(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("samples_done", C.c_uint32), ("depth", C.c_uint32),
+                ("seed", C.c_uint64), ("tag", C.c_uint64)]
+
+
 class rt_scene_opts(C.Structure):
     _fields_ = [("builder", C.c_uint32), ("reserved", C.c_uint32 * 7)]
 
@@ -124,6 +129,10 @@ PROTOTYPES = {
     "rt_trace_paths": (_i, [_vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts), _vp, _vp, _sz, _vp]),
     "rt_trace_path_segments": (_i, [_vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts), _vp, _vp, _sz, _vp, _u32, _vp, _vp, _vp]),
     "rt_write_ppm": (_i, [C.c_char_p, _vp, _u32, _u32]),
+    "rt_finalize": (_i, [_vp, _sz, _u32, _vp]),
+    "rt_checkpoint_save": (_i, [C.c_char_p, _vp, _vp]),
+    "rt_checkpoint_load": (_i, [C.c_char_p, _vp, _vp, _sz]),
+    "rt_hash_bytes": (_u64, [_vp, _sz, _u64]),
     "rt_config_load": (_i, [C.c_char_p, C.POINTER(_vp)]),
     "rt_config_parse": (_i, [C.c_char_p, _sz, C.c_char_p, C.POINTER(_vp)]),
     "rt_config_destroy": (None, [_vp]),

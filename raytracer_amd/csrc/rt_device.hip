@@ -1644,7 +1644,9 @@ int rt_render(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts,
     rc = rt_render_device(scene, cam, opts, d_sum, nullptr);
     if (rc == RT_OK && rgb8) {
         if (hipMalloc(reinterpret_cast<void**>(&d_rgb), n_pixels * 3) != hipSuccess) { cleanup(); return fail(RT_ERR_DEVICE, "rt_render: hipMalloc failed"); }
-        rc = rt_finalize_device(scene, d_sum, n_pixels, opts->sample_end - opts->sample_begin, d_rgb, nullptr);
+        // a running sum handed in with RT_RENDER_ACCUMULATE is taken to hold samples [0, sample_begin)
+        const uint32_t in_sum = (opts->flags & RT_RENDER_ACCUMULATE) ? opts->sample_end : opts->sample_end - opts->sample_begin;
+        rc = rt_finalize_device(scene, d_sum, n_pixels, in_sum, d_rgb, nullptr);
     }
     if (rc == RT_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(RT_ERR_DEVICE, "rt_render: kernel execution failed: %s", hipGetErrorString(hipGetLastError()));
     if (rc == RT_OK && sum_rgb && hipMemcpy(sum_rgb, d_sum, n_pixels * 3 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(RT_ERR_DEVICE, "rt_render: download failed");

@@ -209,4 +209,64 @@ int rt_write_ppm(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t
     return ok ? RT_OK : fail(RT_ERR_IO, "rt_write_ppm: write to %s failed", path);
 }
 
+int rt_finalize(const float* sum_rgb, size_t n_pixels, uint32_t spp_total, uint8_t* rgb8) {
+    if (!sum_rgb || !rgb8) return fail(RT_ERR_INVALID_ARGUMENT, "rt_finalize: null argument");
+    if (spp_total == 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_finalize: zero samples");
+    const double inv_spp = 1.0 / double(spp_total);
+    for (size_t g = 0; g < n_pixels * 3; ++g) {  // the arithmetic of the device's finalize kernel, operation for operation
+        const double x = 255.0 * std::sqrt(inv_spp * double(sum_rgb[g]));
+        uint8_t q = 0;
+        if (x > 0.0) q = (x >= 255.0) ? uint8_t(255) : uint8_t(int(x));
+        rgb8[g] = q;
+    }
+    return RT_OK;
+}
+
+// Checkpoint file: 8-byte magic, rt_checkpoint_info, then width*height*3 floats, all little-endian as in memory.
+static const char kCheckpointMagic[8] = {'R', 'T', 'A', 'C', 'C', 'U', 'M', '1'};
+
+int rt_checkpoint_save(const char* path, const rt_checkpoint_info* info, const float* sum_rgb) {
+    if (!path || !info || !sum_rgb) return fail(RT_ERR_INVALID_ARGUMENT, "rt_checkpoint_save: null argument");
+    if (info->width == 0 || info->height == 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_checkpoint_save: empty image");
+    // write beside the target and rename, so that an interrupted save leaves the previous checkpoint intact
+    const std::string tmp = std::string(path) + ".part";
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return fail(RT_ERR_IO, "rt_checkpoint_save: cannot open %s", tmp.c_str());
+    const size_t n = size_t(info->width) * info->height * 3;
+    bool ok = std::fwrite(kCheckpointMagic, 1, 8, f) == 8 && std::fwrite(info, sizeof *info, 1, f) == 1 &&
+              std::fwrite(sum_rgb, sizeof(float), n, f) == n;
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok || std::rename(tmp.c_str(), path) != 0) {
+        std::remove(tmp.c_str());
+        return fail(RT_ERR_IO, "rt_checkpoint_save: cannot write %s", path);
+    }
+    return RT_OK;
+}
+
+int rt_checkpoint_load(const char* path, rt_checkpoint_info* info, float* sum_rgb, size_t capacity) {
+    if (!path || !info) return fail(RT_ERR_INVALID_ARGUMENT, "rt_checkpoint_load: null argument");
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return fail(RT_ERR_IO, "rt_checkpoint_load: cannot open %s", path);
+    char magic[8];
+    int rc = RT_OK;
+    if (std::fread(magic, 1, 8, f) != 8 || std::memcmp(magic, kCheckpointMagic, 8) != 0 || std::fread(info, sizeof *info, 1, f) != 1) {
+        rc = fail(RT_ERR_IO, "rt_checkpoint_load: %s is not a checkpoint file", path);
+    } else if (info->width == 0 || info->height == 0 || uint64_t(info->width) * info->height > (uint64_t(1) << 32)) {
+        rc = fail(RT_ERR_IO, "rt_checkpoint_load: %s has an implausible header", path);
+    } else if (sum_rgb) {
+        const size_t n = size_t(info->width) * info->height * 3;
+        if (capacity < n) rc = fail(RT_ERR_INVALID_ARGUMENT, "rt_checkpoint_load: buffer of %zu floats, %zu needed", capacity, n);
+        else if (std::fread(sum_rgb, sizeof(float), n, f) != n) rc = fail(RT_ERR_IO, "rt_checkpoint_load: %s is truncated", path);
+    }
+    std::fclose(f);
+    return rc;
+}
+
+uint64_t rt_hash_bytes(const void* bytes, size_t len, uint64_t basis) {
+    uint64_t h = basis ? basis : 0xcbf29ce484222325ull;
+    const unsigned char* p = static_cast<const unsigned char*>(bytes);
+    for (size_t i = 0; i < len; ++i) { h ^= p[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+
 }  // extern "C"

@@ -219,3 +219,63 @@ def test_render_into_file_entry_points(rt, tmp_path):
                                                       2, 10, 0, 0))
     _, want = rt.Scene(spheres).render(cam, 2, depth=10, seed=0, want_sum=False)
     assert np.array_equal(_read_ppm(path), want.reshape(24, 40, 3))
+
+
+def test_checkpoint_file_round_trip(rt, tmp_path):
+    import ctypes as C
+
+    from raytracer_amd import _abi
+
+    info = _abi.rt_checkpoint_info(7, 5, 12, 10, 99, 0xDEADBEEF)
+    sums = np.arange(7 * 5 * 3, dtype=np.float32) * 0.25
+    path = str(tmp_path / "a.rtacc").encode()
+    _abi.check(_abi.lib.rt_checkpoint_save(path, C.byref(info), sums.ctypes.data))
+    got = _abi.rt_checkpoint_info()
+    _abi.check(_abi.lib.rt_checkpoint_load(path, C.byref(got), None, 0))  # header only
+    assert (got.width, got.height, got.samples_done, got.depth, got.seed, got.tag) == (7, 5, 12, 10, 99, 0xDEADBEEF)
+    back = np.zeros_like(sums)
+    _abi.check(_abi.lib.rt_checkpoint_load(path, C.byref(got), back.ctypes.data, back.size))
+    assert np.array_equal(back, sums)
+    assert _abi.lib.rt_checkpoint_load(path, C.byref(got), back.ctypes.data, back.size - 1) == 1  # buffer too small
+    open(tmp_path / "bad", "wb").write(b"P3\n1 1\n255\n")
+    assert _abi.lib.rt_checkpoint_load(str(tmp_path / "bad").encode(), C.byref(got), None, 0) == 4
+    raw = open(path, "rb").read()
+    open(tmp_path / "short", "wb").write(raw[:-8])
+    assert _abi.lib.rt_checkpoint_load(str(tmp_path / "short").encode(), C.byref(got), back.ctypes.data, back.size) == 4
+    # the host finalize follows src/lib.rs:148-149, :186-192: mean, sqrt, x255, truncate, saturate
+    q = np.zeros(4 * 3, dtype=np.uint8)
+    s = np.array([4 * 1.0, 4 * 0.25, 0.0, 4 * 4.0, -1.0, np.nan, 4 * 0.999, 4 * 0.5, 1e-12, 0, 0, 0], dtype=np.float32)
+    _abi.check(_abi.lib.rt_finalize(s.ctypes.data, 4, 4, q.ctypes.data))
+    assert list(q[:9]) == [255, 127, 0, 255, 0, 0, 254, 180, 0]
+    h = _abi.lib.rt_hash_bytes(b"abc", 3, 0)
+    assert h == 0xE71FA2190541574B and _abi.lib.rt_hash_bytes(b"c", 1, _abi.lib.rt_hash_bytes(b"ab", 2, 0)) == h  # FNV-1a, chainable
+
+
+@pytest.mark.gpu
+def test_resumed_render_equals_uninterrupted(rt, tmp_path):
+    from raytracer_amd import _abi
+
+    scene = rt.Scene(rt.gen_scene(1))
+    cam = rt.default_camera(96, 64)
+    whole, q_whole = scene.render(cam, 12, depth=10, seed=5, samples_per_item=4)
+    part, _ = scene.render(cam, 8, depth=10, seed=5, samples_per_item=4)
+    o = scene.opts(8, 12, 10, 5, flags=_abi.RT_RENDER_ACCUMULATE, samples_per_item=4)
+    q = np.zeros((64, 96, 3), dtype=np.uint8)
+    _abi.check(_abi.lib.rt_render(scene.handle, cam.c, o, part.ctypes.data, q.ctypes.data))
+    assert np.array_equal(part, whole) and np.array_equal(q.reshape(q_whole.shape), q_whole)
+    q2 = np.zeros_like(q)
+    _abi.check(_abi.lib.rt_finalize(whole.ctypes.data, 96 * 64, 12, q2.ctypes.data))
+    assert np.array_equal(q2, q)  # host and device finalize agree byte for byte
+    # the command line: two invocations with a checkpoint give the file of one
+    args = [CLI, "-r", "--width", "96", "--height", "64", "--every", "4", "--seed", "5"]
+    a, b, ck = tmp_path / "a.ppm", tmp_path / "b.ppm", tmp_path / "b.rtacc"
+    r = subprocess.run(args + ["-s", "12", "--out", str(a), "--checkpoint", str(tmp_path / "a.rtacc")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    r1 = subprocess.run(args + ["-s", "8", "--out", str(b), "--checkpoint", str(ck)], capture_output=True, text=True, timeout=120)
+    r2 = subprocess.run(args + ["-s", "12", "--out", str(b), "--checkpoint", str(ck)], capture_output=True, text=True, timeout=120)
+    assert r1.returncode == 0 and r2.returncode == 0, r1.stderr + r2.stderr
+    assert "Continuing from" in r2.stdout and "8 samples per pixel done" in r2.stdout
+    assert open(a).read() == open(b).read()
+    assert np.array_equal(_read_ppm(a), q_whole.reshape(64, 96, 3))
+    other = subprocess.run(args[:-1] + ["6", "-s", "12", "--out", str(b), "--checkpoint", str(ck)], capture_output=True, text=True, timeout=120)
+    assert other.returncode == 101 and "another scene, frame, depth or seed" in other.stderr
