@@ -141,7 +141,7 @@ def main():
                        "image_mean_u8": round(img_mean, 3)},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": roofline.PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / roofline.PEAK_FP32_TFLOPS, 5), "traffic": None,
-                         "kernel": "render_kernel", "kernel_ms": round(render_ms, 3),
+                         "kernel": "render_kernel_ws<true, 512, false> (+ combine_kernel, 0.02 ms)", "kernel_ms": round(render_ms, 3),
                          "algorithmic_flops_per_path": round(fpp, 1), "segments_per_path": seg,
                          "note": "FP32 vector-ALU bound (BVH and spheres are cache resident, no dense contraction so no MFMA); "
                                  "algorithmic flops = reference arithmetic with a 2*ceil(log2 N)-box traversal model"},
