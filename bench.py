@@ -77,8 +77,15 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the render path has no CPU fallback")
+    # BENCH_REHEARSE=1: all ranks share the visible GPUs and reduce over gloo through host memory — a functional
+    # rehearsal of the N > 1 path on a box with fewer GPUs than ranks (not a measurement)
+    rehearse = os.environ.get("BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 and rehearse:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     hittables = rt.gen_scene(SCENE_SEED)
@@ -97,7 +104,11 @@ def main():
         ev0.record()
         scene.render_device(cam, d_sum.data_ptr(), begin, end, DEPTH, SEED, stream=stream, flags=args.kernel_flags)
         ev1.record()
-        if world > 1:
+        if world > 1 and rehearse:
+            host = d_sum.cpu()
+            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+            d_sum.copy_(host)
+        elif world > 1:
             dist.reduce(d_sum, dst=0, op=dist.ReduceOp.SUM)
         if rank == 0:
             scene.finalize_device(d_sum.data_ptr(), n_pixels, total_spp, d_rgb.data_ptr(), stream=stream)
@@ -118,7 +129,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     render_ms = sum(a.elapsed_time(b) for a, b in kernel_ms) / max(len(kernel_ms), 1)
@@ -127,14 +138,16 @@ def main():
         paths_per_step = n_pixels * total_spp
         value = paths_per_step * args.steps / elapsed / 1e6
         base = cpu_baseline(hittables, args.cpu_seconds) if (args.cpu_seconds > 0 and world == 1) else None
-        seg = base["segments_per_path"] if base else 3.3
+        # segments per path of this workload: counted by the CPU leg when it runs, else the value it counts
+        # (a property of scene, camera, depth and sampling rule, not of the machine)
+        seg = base["segments_per_path"] if base else roofline.C2_SEGMENTS_PER_PATH
         fpp = roofline.flops_per_path(len(hittables), seg)
         achieved = (n_pixels * (end - begin)) * fpp / (render_ms * 1e-3) / 1e12 if render_ms > 0 else 0.0
         img_mean = float(d_rgb.float().mean().item())
         line = {
             "metric": "Mpaths/sec at 1920x1080 random-spheres", "value": round(value, 3), "unit": "Mpaths/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not rehearse else "synthetic; REHEARSAL on shared GPUs over gloo, not a measurement",
             "config": {"workload": "random-spheres 488 spheres (seed 1), 1920x1080, %d spp per GPU (%d total), depth %d"
                                    % (SPP_PER_GPU, total_spp, DEPTH),
                        "paths_per_step": paths_per_step, "parallelism": "sample-split x%d + RCCL sum-reduce" % world,

@@ -27,3 +27,8 @@ def flops_per_path(n_spheres, segments_per_path):
 
 def bytes_per_segment(n_spheres):
     return 2 * math.ceil(math.log2(max(n_spheres, 2))) * NODE_BYTES + SPHERE_BYTES
+
+
+# Mean segments per path of the bench workload (random spheres seed 1, default camera, depth 50), as counted by the
+# CPU oracle in the reference's configuration; bench.py uses it when its CPU leg is skipped (N > 1, --cpu-seconds 0).
+C2_SEGMENTS_PER_PATH = 2.0263
