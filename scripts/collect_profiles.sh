@@ -13,7 +13,7 @@ cp "$out/pmc/summary.txt" "$out/bench_pmc_summary.txt"
 timeout -k 10 300 python3 bench.py > "$out/bench.log" 2>&1 || { echo "bench failed"; tail -5 "$out/bench.log"; exit 1; }
 tail -n 1 "$out/bench.log" > "$out/bench_line.json"
 : > "$out/configs.jsonl"; : > "$out/configs_with_phase_stats.jsonl"
-for c in c1 c2 c2d10 c4 c5; do
+for c in c1 c2 c2d10 c3 c4 c5; do
   timeout -k 10 200 python3 scripts/run_config.py $c --steps 5 2>/dev/null | tail -n 1 >> "$out/configs.jsonl" || { echo "config $c failed"; exit 1; }
   timeout -k 10 200 python3 scripts/run_config.py $c --steps 1 --stats 2>/dev/null | tail -n 1 >> "$out/configs_with_phase_stats.jsonl" || { echo "config $c stats failed"; exit 1; }
 done

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Times one of the parity/stress configurations on cuda:0 and prints one JSON line.
 
-    python scripts/run_config.py c2|c2d10|c4|c5|c1 [--spp N] [--stats]
+    python scripts/run_config.py c1|c2|c2d10|c3|c4|c5 [--spp N] [--stats]
 
 c1 bundled scene.json 512x512 (disc + emitter + texture, linear path)   c2 random spheres 1080p depth 50
-c2d10 the same at the reference's depth 10    c4 earth + nested glass shells    c5 1M spheres 1080p 64 spp
+c2d10 the same at the reference's depth 10    c3 one GPU's share (125 of 1000 spp) of the same scene at 3840x2160    c4 earth + nested glass shells    c5 1M spheres 1080p 64 spp
 """
 import argparse
 import json
@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--builder", default="sah", choices=["sah", "lbvh"])
+    ap.add_argument("--chunk", type=int, default=0, help="samples per work item (0 = chosen by the library)")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -37,6 +38,8 @@ def main():
     t0 = time.time()
     if a.config in ("c2", "c2d10"):
         h, tex, cam, spp, depth = rt.gen_scene(1), [], rt.default_camera(a.width, a.height), 100, (50 if a.config == "c2" else 10)
+    elif a.config == "c3":  # one GPU's share of the 8-GPU configuration: samples [0, 125) of 1000 at 3840x2160
+        h, tex, cam, spp, depth = rt.gen_scene(1), [], rt.default_camera(3840, 2160), 125, 50
     elif a.config == "c4":
         h, tex, spp, depth = rt.gen_scene_shells(8), [earth], 100, 50
         cam = rt.Camera.build([0, 0, 1], [0, 1.5, -5], 1.0, 0.1, 1920, 1080)
@@ -56,13 +59,13 @@ def main():
     d_sum = torch.zeros(H, W, 3, dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     flags = a.flags | (_abi.RT_RENDER_STATS if a.stats else 0)
-    scene.render_device(cam, d_sum.data_ptr(), 0, spp, depth, 0, stream=stream, flags=flags)
+    scene.render_device(cam, d_sum.data_ptr(), 0, spp, depth, 0, stream=stream, flags=flags, samples_per_item=a.chunk)
     torch.cuda.synchronize()
     ms = []
     for _ in range(a.steps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        scene.render_device(cam, d_sum.data_ptr(), 0, spp, depth, 0, stream=stream, flags=flags)
+        scene.render_device(cam, d_sum.data_ptr(), 0, spp, depth, 0, stream=stream, flags=flags, samples_per_item=a.chunk)
         e1.record()
         torch.cuda.synchronize()
         ms.append(e0.elapsed_time(e1))
