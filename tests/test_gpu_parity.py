@@ -204,6 +204,9 @@ def test_all_render_schedules_give_the_same_image(scene1, rt):
     b, _ = scene1.render(cam, 6, depth=50, seed=8, flags=_abi.RT_RENDER_KERNEL_LOCKSTEP)
     c, _ = scene1.render(cam, 6, depth=50, seed=8, flags=_abi.RT_RENDER_KERNEL_NO_LDS_SCENE)
     assert np.array_equal(a, b) and np.array_equal(a, c)
+    # the instrumented build runs the inner-node loop as compiled C++, the production build in assembly
+    e, _ = scene1.render(cam, 6, depth=50, seed=8, flags=_abi.RT_RENDER_STATS)
+    assert np.array_equal(a, e)
     # and the image is the sum, in sample order, of the colours trace_paths returns path by path
     px = np.repeat(np.arange(200 * 120, dtype=np.uint32), 6)
     sm = np.tile(np.arange(6, dtype=np.uint32), 200 * 120)
