@@ -634,9 +634,10 @@ __global__ __launch_bounds__(kBlock) void render_kernel(SceneDev S, CamDev C, Re
 // lane no longer walks "traverse, then shade" in lock step with its wave:
 //   * a wave keeps stepping its BVH descents while at least kTravThreshold lanes
 //     are still descending; lanes that finished wait for the shade phase;
-//   * inside that, inner-node steps (f32) run until fewer than kInnerThreshold
-//     lanes sit on an inner node, then every lane parked on a leaf runs the f64
-//     sphere test together;
+//   * inside that, a run of inner-node steps (f32) lasts until fewer than
+//     kInnerThreshold lanes sit on an inner node or kLeaveThreshold lanes have
+//     left the inner nodes since the run began, then every lane parked on a leaf
+//     runs the f64 sphere test together;
 //   * the shade phase scatters / terminates / regenerates all waiting lanes at
 //     once and sends them back into the descent.
 // With LDS16 the whole scene is staged in LDS: boxes as f16 (rounded outward, so
