@@ -49,8 +49,19 @@ struct TexImgDev {
     uint32_t w, h;
 };
 
+// Node of the HBM-resident tree as the render kernel reads it: the boxes of both children on a 16-bit grid over
+// the scene box (plane = qbase + q * qstep per axis; lower bounds rounded down, upper bounds up, so the boxes only
+// grow) + 2 child links: 32 bytes = two 16-byte loads per lane instead of the four of the f32 Node.
+struct Node32 {
+    uint16_t q[12];  // lo0.xyz hi0.xyz lo1.xyz hi1.xyz
+    int32_t child0, child1;
+};
+static_assert(sizeof(Node32) == 32, "Node32 must be 32 bytes");
+
 struct SceneDev {
     const Node* nodes;
+    const Node32* nodes32;  // the same tree, quantised (render_kernel_ws without the scene in LDS)
+    float qbase[3], qstep[3];
     const double4* sph;     // the n_tree spheres of the BVH in leaf order, then the n_wide spheres kept out of it
     const DiscDev* discs;   // scene order
     const float4* mat;      // spheres in leaf order, then discs: albedo rgb + (fuzz | refractive index)
@@ -690,6 +701,9 @@ __device__ __forceinline__ bool sphere_candidate(const double4 s, int32_t k, int
     return better;
 }
 
+// QUANT: the boxes will come as grid indices q (Node32), plane = qbase + q * qstep: the grid is folded into the
+// per-ray factors, t = fma(q, qstep / d, (qbase - (o +- eps)) / d), the same count of roundings as with f32 planes.
+template <bool QUANT>
 __device__ __forceinline__ void trav_begin(const SceneDev& S, const Tables& Tb, const Path& p, Trav& T) {
     T.best.t = 0.0;
     T.best.k = -1;
@@ -714,9 +728,15 @@ __device__ __forceinline__ void trav_begin(const SceneDev& S, const Tables& Tb, 
     for (int a = 0; a < 3; ++a) {
         const float d = df[a];
         const float i = (fabsf(d) >= 1.0e-18f) ? fast_rcp(d) : copysignf(1.0e18f, d);
-        T.inv[a] = i;
-        T.A[a] = -(of[a] + S.eps) * i;
-        T.B[a] = -(of[a] - S.eps) * i;
+        if (QUANT) {
+            T.inv[a] = S.qstep[a] * i;
+            T.A[a] = (S.qbase[a] - (of[a] + S.eps)) * i;
+            T.B[a] = (S.qbase[a] - (of[a] - S.eps)) * i;
+        } else {
+            T.inv[a] = i;
+            T.A[a] = -(of[a] + S.eps) * i;
+            T.B[a] = -(of[a] - S.eps) * i;
+        }
     }
     T.tmax = (T.best.k >= 0) ? float(T.best.t) * (1.0f + 4.0e-7f) : 3.0e38f;
 }
@@ -778,11 +798,14 @@ __device__ __forceinline__ void inner_step(const SceneDev& S, const uint4* lds_q
         c0 = int32_t(b.z);
         c1 = int32_t(b.w);
     } else {
-        const float4* q = reinterpret_cast<const float4*>(S.nodes + T.node);
-        const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-        slab2(T, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, &en0, &ex0, &en1, &ex1);
-        c0 = __float_as_int(q3.x);
-        c1 = __float_as_int(q3.y);
+        const uint4* q = reinterpret_cast<const uint4*>(S.nodes32 + T.node);
+        const uint4 a = q[0], b = q[1];
+        // a.x = lo0.x lo0.y  a.y = lo0.z hi0.x  a.z = hi0.y hi0.z  a.w = lo1.x lo1.y  b.x = lo1.z hi1.x  b.y = hi1.y hi1.z
+        slab2(T, float(a.x & 0xffffu), float(a.x >> 16), float(a.y & 0xffffu), float(a.y >> 16), float(a.z & 0xffffu),
+              float(a.z >> 16), float(a.w & 0xffffu), float(a.w >> 16), float(b.x & 0xffffu), float(b.x >> 16),
+              float(b.y & 0xffffu), float(b.y >> 16), &en0, &ex0, &en1, &ex1);
+        c0 = int32_t(b.z);
+        c1 = int32_t(b.w);
     }
     descend<BLOCK>(T, en0, ex0, en1, ex1, c0, c1, stk);
 }
@@ -1012,7 +1035,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel_ws(SceneDev S, CamDev C, 
                 } else if (!scatter_part(P, p, sf, r)) {
                     alive = false;  // bounded fuzz loop gave up: the path contributes nothing
                 }
-                if (alive) trav_begin(S, Tb, p, T);
+                if (alive) trav_begin<!LDS16>(S, Tb, p, T);
             }
         }
         if (__all(done)) break;
@@ -1500,6 +1523,48 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
             if ((rc = upload(sc, n16, &sc->d_nodes16)) != RT_OK) return bail(rc);
             sc->lds16_scene_bytes = scene_bytes;
         }
+    }
+    {
+        // 16-bit grid over the box of the tree's spheres; base and step are f32 values first, the indices are then
+        // chosen in f64 against exactly those values, so that base + q * step never cuts into a box
+        double glo[3], ghi[3];
+        for (int a = 0; a < 3; ++a) { glo[a] = bvh.scene_lo[a]; ghi[a] = bvh.scene_hi[a]; }
+        for (const Node& nd : bvh.nodes)
+            for (int a = 0; a < 3; ++a) {
+                if (nd.lo0[a] < 3.0e38f) { glo[a] = std::min(glo[a], double(nd.lo0[a])); ghi[a] = std::max(ghi[a], double(nd.hi0[a])); }
+                if (nd.lo1[a] < 3.0e38f) { glo[a] = std::min(glo[a], double(nd.lo1[a])); ghi[a] = std::max(ghi[a], double(nd.hi1[a])); }
+            }
+        float base[3], step[3];
+        for (int a = 0; a < 3; ++a) {
+            base[a] = std::nextafter(float(glo[a]), -INFINITY);
+            step[a] = std::nextafter(float(std::max(ghi[a] - double(base[a]), 1.0e-30) / 65535.0), INFINITY);
+            sc->dev.qbase[a] = base[a];
+            sc->dev.qstep[a] = step[a];
+        }
+        auto q_down = [&](float v, int a) -> uint16_t {
+            if (!(v < 3.0e38f)) return 65535;  // the far-away point box of a single-sphere tree becomes the grid's far corner
+            double q = std::floor((double(v) - double(base[a])) / double(step[a]));
+            q = std::min(std::max(q, 0.0), 65535.0);
+            while (q > 0.0 && double(base[a]) + q * double(step[a]) > double(v)) q -= 1.0;
+            return uint16_t(q);
+        };
+        auto q_up = [&](float v, int a) -> uint16_t {
+            if (!(v < 3.0e38f)) return 65535;
+            double q = std::ceil((double(v) - double(base[a])) / double(step[a]));
+            q = std::min(std::max(q, 0.0), 65535.0);
+            while (q < 65535.0 && double(base[a]) + q * double(step[a]) < double(v)) q += 1.0;
+            return uint16_t(q);
+        };
+        std::vector<Node32> n32(bvh.nodes.size());
+        for (size_t i = 0; i < bvh.nodes.size(); ++i) {
+            const Node& nd = bvh.nodes[i];
+            for (int a = 0; a < 3; ++a) {
+                n32[i].q[a] = q_down(nd.lo0[a], a); n32[i].q[3 + a] = q_up(nd.hi0[a], a);
+                n32[i].q[6 + a] = q_down(nd.lo1[a], a); n32[i].q[9 + a] = q_up(nd.hi1[a], a);
+            }
+            n32[i].child0 = nd.child0; n32[i].child1 = nd.child1;
+        }
+        if ((rc = upload(sc, n32, &sc->dev.nodes32)) != RT_OK) return bail(rc);
     }
     if ((rc = upload(sc, bvh.nodes, &sc->dev.nodes)) != RT_OK) return bail(rc);
     if ((rc = upload(sc, h_sph, &sc->dev.sph)) != RT_OK) return bail(rc);

@@ -84,7 +84,7 @@ def main():
                         "shade_visits_per_path": round(seg, 3), "inner_lane_util": round(o[1] / max(o[0], 1), 3),
                         "leaf_lane_util": round(o[3] / max(o[2], 1), 3), "shade_lane_util": round(o[5] / max(o[4], 1), 3)}
         out["algorithmic_bytes_per_segment"] = roofline.bytes_per_segment(len(h))
-        out["executed_node_bytes_per_path"] = round(o[1] / paths * 64 + o[3] / paths * 32, 1)
+        out["executed_node_bytes_per_path"] = round(o[1] / paths * 32 + o[3] / paths * 32, 1)  # 32-byte nodes (f16 in LDS or 16-bit grid in HBM), 32-byte spheres
     print(json.dumps(out), flush=True)
 
 
