@@ -541,7 +541,7 @@ __device__ __forceinline__ void flush_item(const RenderParams& P, float* sum_rgb
 // Work hand-out.  A work item is one 8x8 pixel tile x one chunk of samples.  A wave draws an item from
 // the global counter with ONE atomic and deals its 64 pixels to its lanes as they ask, so the counter
 // sees one request per item instead of one per pixel (a single word serves only ~90 requests per
-// microsecond).  ws = this wave's two LDS words {item, next undealt pixel of its tile}; called by the
+// microsecond).  ws = this wave's four LDS words {item, next undealt pixel of its tile, tile origin x | y << 16, chunk}; called by the
 // lanes that need work.  Chunks keep the items small enough to balance the end of the launch: with one
 // item per pixel and 100 samples each, a third of the launch was spent waiting for the last items.
 __device__ __forceinline__ void claim_pixels(bool& need, bool& done, uint32_t& pixel, uint32_t& xy, uint32_t& chunk, volatile uint32_t* ws,
@@ -551,12 +551,18 @@ __device__ __forceinline__ void claim_pixels(bool& need, bool& done, uint32_t& p
     unsigned long long m = __ballot(need);
     while (m) {
         uint32_t item = ws[0], next = ws[1];
-        if (next >= 64u) {
+        if (next >= 64u) {  // the tile is dealt out: draw the next item and decode it once for its 64 pixels
             const int first = __ffsll((long long)m) - 1;
             uint32_t w = 0;
             if (int(lane) == first) w = atomicAdd(work_counter, 1u);
             item = uint32_t(__shfl(int(w), first));
             next = 0;
+            if (item < n_items) {
+                const uint32_t tile = item / P.n_chunks;
+                const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+                ws[2] = (tx * 8u) | ((ty * 8u) << 16);
+                ws[3] = item - tile * P.n_chunks;
+            }
         }
         if (item >= n_items) {  // nothing left: remember it, so later calls cost no atomic
             if (need) { done = true; need = false; }
@@ -568,10 +574,10 @@ __device__ __forceinline__ void claim_pixels(bool& need, bool& done, uint32_t& p
         const uint32_t avail = 64u - next;
         if (need && rank < avail) {
             const uint32_t in_tile = next + rank;  // row-major inside the tile
-            const uint32_t tile = item / P.n_chunks;
-            const uint32_t x = (tile % P.tiles_x) * 8u + (in_tile & 7u);
-            const uint32_t y = (tile / P.tiles_x) * 8u + (in_tile >> 3);
-            if (x < C.W && y < C.H) { pixel = y * C.W + x; xy = x | (y << 16); chunk = item % P.n_chunks; need = false; }  // outside the frame: ask again
+            const uint32_t origin = ws[2];
+            const uint32_t x = (origin & 0xffffu) + (in_tile & 7u);
+            const uint32_t y = (origin >> 16) + (in_tile >> 3);
+            if (x < C.W && y < C.H) { pixel = y * C.W + x; xy = x | (y << 16); chunk = ws[3]; need = false; }  // outside the frame: ask again
         }
         const uint32_t asked = uint32_t(__popcll(m));
         ws[0] = item;
@@ -591,7 +597,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(SceneDev S, CamDev C, Re
                                                         uint32_t* __restrict__ work_counter) {
     extern __shared__ int32_t stack_lds[];
     int32_t* stk = stack_lds + threadIdx.x;
-    volatile uint32_t* wave_state = reinterpret_cast<uint32_t*>(stack_lds + stack_depth * kBlock) + 2 * (threadIdx.x >> 6);
+    volatile uint32_t* wave_state = reinterpret_cast<uint32_t*>(stack_lds + stack_depth * kBlock) + 4 * (threadIdx.x >> 6);
     if ((threadIdx.x & 63) == 0) { wave_state[0] = 0; wave_state[1] = 64; }
 
     Path p;
@@ -929,7 +935,7 @@ __device__ __forceinline__ void leaf_step(const Tables& Tb, const Path& p, Trav&
 // work_counter[8..15] = {inner turns*64, inner lanes, leaf turns*64, leaf lanes, shade turns*64, shading
 // lanes, lanes that regenerated, descent-loop turns*64}.
 template <bool LDS16, int BLOCK, bool STATS>
-__global__ __launch_bounds__(BLOCK) void render_kernel_ws(SceneDev S, CamDev C, RenderParams P,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void render_kernel_ws(SceneDev S, CamDev C, RenderParams P,
                                                           const Node16* __restrict__ nodes16, uint32_t stack_depth,
                                                           float* __restrict__ sum_rgb, float* __restrict__ partials,
                                                           uint32_t* __restrict__ work_counter) {
@@ -946,7 +952,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel_ws(SceneDev S, CamDev C, 
     uint4* lds_id = lds_kind + (LDS16 ? quads : 0);
     int32_t* stk0 = reinterpret_cast<int32_t*>(lds_id + (LDS16 ? quads : 0));
     int32_t* stk = stk0 + threadIdx.x;
-    volatile uint32_t* wave_state = reinterpret_cast<uint32_t*>(stk0 + stack_depth * BLOCK) + 2 * (threadIdx.x >> 6);
+    volatile uint32_t* wave_state = reinterpret_cast<uint32_t*>(stk0 + stack_depth * BLOCK) + 4 * (threadIdx.x >> 6);
     if ((threadIdx.x & 63) == 0) { wave_state[0] = 0; wave_state[1] = 64; }
     stk[0] = kLeafSentinel;
     if (LDS16) {
@@ -1269,8 +1275,8 @@ float descent_eps(const rt_scene* sc, double origin_abs) {
     return float(extent * (1.0 / 2097152.0));  // 2^-21 of the largest distance between a box plane and an origin
 }
 
-// LDS of the 256-thread kernels: the traversal stack plus two words of pixel hand-out state per wave
-size_t stack_bytes(const rt_scene* sc) { return size_t(std::max<uint32_t>(sc->stack_depth, 1u)) * kBlock * sizeof(int32_t) + 64; }
+// LDS of the 256-thread kernels: the traversal stack plus four words of pixel hand-out state per wave
+size_t stack_bytes(const rt_scene* sc) { return size_t(std::max<uint32_t>(sc->stack_depth, 1u)) * kBlock * sizeof(int32_t) + 64; }  // 16 bytes of hand-out state per wave
 
 int check_render_args(const rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, const char* who) {
     if (!scene || !cam || !opts) return fail(RT_ERR_INVALID_ARGUMENT, "%s: null argument", who);
@@ -1643,7 +1649,7 @@ int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_render_opts
                            std::max<uint32_t>(scene->stack_depth, 1u), d_sum_rgb, scene->d_partials, scene->d_work_counter);
     } else if (scene->d_nodes16 && !(opts->flags & RT_RENDER_KERNEL_NO_LDS_SCENE)) {
         constexpr int B = 512;
-        const size_t lds = scene->lds16_scene_bytes + size_t(std::max<uint32_t>(scene->stack_depth, 1u)) * B * sizeof(int32_t) + 64;
+        const size_t lds = scene->lds16_scene_bytes + size_t(std::max<uint32_t>(scene->stack_depth, 1u)) * B * sizeof(int32_t) + 16 * (B / 64);
         auto k = (opts->flags & RT_RENDER_STATS) ? render_kernel_ws<true, B, true> : render_kernel_ws<true, B, false>;
         RT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, B, lds));
