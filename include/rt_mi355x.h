@@ -177,6 +177,10 @@ int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_render_opts
  * regenerating, lanes regenerating, descent-loop turns*64}.  Synchronises the device. */
 int rt_debug_render_stats(rt_scene* scene, uint64_t out[8]);
 
+/* Measurement aid: how rt_render_device launches its kernel for this scene on this device: threads per workgroup,
+ * workgroups the runtime can keep resident per CU (registers and LDS), and the waves per SIMD that follow. */
+int rt_debug_render_launch(rt_scene* scene, uint32_t* block_threads, uint32_t* workgroups_per_cu, uint32_t* waves_per_simd);
+
 /* Chunk size rt_render_device uses for this frame and sample range (the summation order of the image). */
 int rt_render_chunk(const rt_camera* cam, const rt_render_opts* opts, uint32_t* samples_per_item);
 

@@ -121,6 +121,7 @@ PROTOTYPES = {
     "rt_scene_get_info": (_i, [_vp, C.POINTER(rt_scene_info)]),
     "rt_render_device": (_i, [_vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts), _vp, _vp]),
     "rt_debug_render_stats": (_i, [_vp, _vp]),
+    "rt_debug_render_launch": (_i, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "rt_render_chunk": (_i, [C.POINTER(rt_camera), C.POINTER(rt_render_opts), C.POINTER(_u32)]),
     "rt_finalize_device": (_i, [_vp, _vp, _sz, _u32, _vp, _vp]),
     "rt_render": (_i, [_vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts), _vp, _vp]),

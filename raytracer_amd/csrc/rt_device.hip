@@ -659,6 +659,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(SceneDev S, CamDev C, Re
 //     once and sends them back into the descent.
 // With LDS16 the whole scene is staged in LDS: boxes as f16 (rounded outward, so
 // the descent stays conservative), child links as int32, spheres as f64.
+constexpr int kBlockLds = 512;      // workgroup of the LDS-resident kernel: 2 per CU = 16 waves = 4 per SIMD (128 VGPRs)
 constexpr int kTravThreshold = 12;
 constexpr int kMaxWide = 4;         // spheres kept out of the tree at most (tested linearly per segment)
 constexpr int kInnerThreshold = 8;
@@ -1648,7 +1649,7 @@ int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_render_opts
         hipLaunchKernelGGL(render_kernel, grid_for(per_cu, kBlock), dim3(kBlock), lds, st, S, C, P,
                            std::max<uint32_t>(scene->stack_depth, 1u), d_sum_rgb, scene->d_partials, scene->d_work_counter);
     } else if (scene->d_nodes16 && !(opts->flags & RT_RENDER_KERNEL_NO_LDS_SCENE)) {
-        constexpr int B = 512;
+        constexpr int B = kBlockLds;
         const size_t lds = scene->lds16_scene_bytes + size_t(std::max<uint32_t>(scene->stack_depth, 1u)) * B * sizeof(int32_t) + 16 * (B / 64);
         auto k = (opts->flags & RT_RENDER_STATS) ? render_kernel_ws<true, B, true> : render_kernel_ws<true, B, false>;
         RT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
@@ -1684,6 +1685,26 @@ int rt_debug_render_stats(rt_scene* scene, uint64_t out[8]) {
     RT_HIP(hipSetDevice(scene->device));
     RT_HIP(hipDeviceSynchronize());
     RT_HIP(hipMemcpy(out, scene->d_work_counter + 8, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_debug_render_launch(rt_scene* scene, uint32_t* block_threads, uint32_t* workgroups_per_cu, uint32_t* waves_per_simd) {
+    if (!scene || !block_threads || !workgroups_per_cu || !waves_per_simd) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_render_launch: null argument");
+    RT_HIP(hipSetDevice(scene->device));
+    int per_cu = 0, block = 0;
+    if (scene->d_nodes16) {
+        block = kBlockLds;
+        const size_t lds = scene->lds16_scene_bytes + size_t(std::max<uint32_t>(scene->stack_depth, 1u)) * kBlockLds * sizeof(int32_t) + 16 * (kBlockLds / 64);
+        auto k = render_kernel_ws<true, kBlockLds, false>;
+        RT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, block, lds));
+    } else {
+        block = kBlock;
+        RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel_ws<false, kBlock, false>, block, stack_bytes(scene)));
+    }
+    *block_threads = uint32_t(block);
+    *workgroups_per_cu = uint32_t(per_cu);
+    *waves_per_simd = uint32_t(per_cu * (block / 64) / 4);
     return RT_OK;
 }
 

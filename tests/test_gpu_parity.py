@@ -486,3 +486,18 @@ def test_lbvh_builder_million_spheres(rt):
     ra, _ = lb.render(cam, 1, depth=50, seed=0, want_rgb8=False)
     rb, _ = sah.render(cam, 1, depth=50, seed=0, want_rgb8=False)
     assert np.array_equal(ra, rb)
+
+
+def test_render_kernel_keeps_its_occupancy(rt, scene1):
+    # one register too many (129 instead of 128) once cut a quarter of the resident waves and cost 40 % of the speed
+    import ctypes as C
+
+    from raytracer_amd import _abi
+
+    b, w, s = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    _abi.check(_abi.lib.rt_debug_render_launch(scene1.handle, C.byref(b), C.byref(w), C.byref(s)))
+    assert (b.value, w.value, s.value) == (512, 2, 4)
+    big = rt.Scene(rt.gen_scene_grid(1, 60))  # 3601 spheres: too large for LDS
+    assert big.info["lds_resident"] == 0
+    _abi.check(_abi.lib.rt_debug_render_launch(big.handle, C.byref(b), C.byref(w), C.byref(s)))
+    assert b.value == 256 and s.value >= 4
