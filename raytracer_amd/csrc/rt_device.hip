@@ -697,10 +697,11 @@ __device__ __forceinline__ bool sphere_candidate(const double4 s, int32_t k, int
         const double sq = __dsqrt_rn(discrm);
         const double t_smaller = -0.5 * (b + sq);
         const double t_larger = t_smaller + sq;
+        // `&` and `|` on purpose: every comparison is evaluated, the wave takes no branch
         const bool near_ok = t_smaller > 0.0;
-        const bool hit = !(discrm < 0.0) && (near_ok || t_larger > 1.0e-6);
+        const bool hit = bool(int(!(discrm < 0.0)) & (int(near_ok) | int(t_larger > 1.0e-6)));
         t = near_ok ? t_smaller : t_larger;
-        better = enabled && hit && (best.k < 0 || t < best.t || (t == best.t && id < best.id));
+        better = bool(int(enabled) & int(hit) & (int(best.k < 0) | int(t < best.t) | (int(t == best.t) & int(id < best.id))));
     }
     best.t = better ? t : best.t;
     best.k = better ? k : best.k;
