@@ -501,3 +501,41 @@ def test_render_kernel_keeps_its_occupancy(rt, scene1):
     assert big.info["lds_resident"] == 0
     _abi.check(_abi.lib.rt_debug_render_launch(big.handle, C.byref(b), C.byref(w), C.byref(s)))
     assert b.value == 256 and s.value >= 4
+
+
+def test_wide_spheres_outside_the_tree(rt, ob):
+    """Spheres whose box covers most of the others are tested per segment instead of through the tree; which
+    spheres those are must not change any hit."""
+    rng = np.random.default_rng(11)
+    grey = rt.diffuse([.5, .5, .5])
+    small = [rt.sphere(list(rng.uniform(-3, 3, 3)), 0.3, grey) for _ in range(30)]
+    cases = {
+        # name: (hittables, wide spheres expected)
+        "big_and_small": ([rt.sphere([0, 0, 0], 50.0, grey), rt.sphere([1, 0, 0], 0.5, grey)], 1),
+        "concentric_pair": ([rt.sphere([0, 0, 0], 2.0, grey), rt.sphere([0, 0, 0], 1.0, grey)], 1),
+        "three_shells_and_crowd": ([rt.sphere([0, 0, 0], 40.0, grey), rt.sphere([0, 0, 0], 30.0, rt.dielectric(1.5)),
+                                    rt.sphere([0.5, 0, 0], 20.0, rt.dielectric(1.5))] + small, 3),
+        "many_shells": ([rt.sphere([0, 0, 0], 10.0 + i, rt.dielectric(1.5)) for i in range(7)] + small, 4),  # at most four
+        "no_wide": (small, 0),
+    }
+    for name, (items, n_wide) in cases.items():
+        h = rt.hittables(items)
+        scene = rt.Scene(h)
+        assert scene.info["n_wide"] == n_wide, name
+        assert scene.info["n_spheres"] == len(items)
+        o = rng.uniform(-6, 6, (6000, 3)).astype(np.float32)
+        d = rng.normal(size=(6000, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        ids, t, nrm = scene.trace_primary(o, d)
+        want_ids, want_t, want_n, _ = ob.Scene(h).trace(o, d, ob.TRAVERSE_GATED_BRUTE)
+        _check_hits(ids, t, nrm, want_ids, want_t, want_n)
+        assert len(np.unique(want_ids)) >= min(len(items), 3), name
+        # the render kernels (wide spheres in trav_begin) against the per-path entry point (wide spheres in closest_hit)
+        cam = rt.Camera.build([0, 0, 0], [0, 1, -5], 1.0, 0.1, 64, 48)
+        img, _ = scene.render(cam, 3, depth=20, seed=2)
+        px = np.repeat(np.arange(64 * 48, dtype=np.uint32), 3)
+        sm = np.tile(np.arange(3, dtype=np.uint32), 64 * 48)
+        cols = scene.trace_paths(cam, px, sm, depth=20, seed=2).reshape(64 * 48, 3, 3)
+        total = np.zeros((64 * 48, 3), dtype=np.float32)
+        for k in range(3):
+            total += cols[:, k, :]
+        assert np.array_equal(total.reshape(48, 64, 3), img), name
