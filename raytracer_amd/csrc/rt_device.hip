@@ -925,6 +925,111 @@ __device__ __forceinline__ void inner_loop_lds16(Trav& T, uint32_t q0_addr, uint
           "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
 }
 
+// The same loop for the tree in HBM (Node32: boxes as 16-bit grid indices, the grid folded into T.inv / T.A / T.B
+// by trav_begin<true>): two 16-byte global loads per node, 12 conversions + 12 FMAs instead of the 12 mixed FMAs.
+template <int BLOCK>
+__device__ __forceinline__ void inner_loop_hbm(Trav& T, const Node32* nodes32, uint32_t stk_addr, int32_t thr) {
+    static_assert(BLOCK == 512 || BLOCK == 256, "stack column stride");
+    constexpr int kShift = (BLOCK == 512) ? 11 : 10;  // log2(BLOCK * sizeof(int32_t))
+    int32_t lanes_on_inner;
+    asm volatile(
+        "1:\n\t"
+        "v_cmp_lt_i32_e32 vcc, -1, %[node]\n\t"
+        "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
+        "s_cmp_ge_i32 %[cnt], %[thr]\n\t"
+        "s_cbranch_scc1 3f\n\t"
+        "s_cmp_eq_u32 %[cnt], 0\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "v_cmp_lt_u32_e64 s[90:91], %[sentinel], %[node]\n\t"  // as unsigned: above the sentinel = a leaf
+        "s_cmp_lg_u64 s[90:91], 0\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "3:\n\t"
+        "s_and_saveexec_b64 s[88:89], vcc\n\t"
+        "v_lshlrev_b32_e32 v112, 5, %[node]\n\t"
+        "global_load_dwordx4 v[120:123], v112, %[base]\n\t"
+        "global_load_dwordx4 v[124:127], v112, %[base] offset:16\n\t"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+        // child 0: v120 = lo.x lo.y | v121 = lo.z hi.x | v122 = hi.y hi.z as 16-bit grid indices
+        "v_cvt_f32_u32_sdwa v112, v120 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
+        "v_fma_f32 v112, v112, %[ix], %[ax]\n\t"
+        "v_cvt_f32_u32_sdwa v113, v121 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+        "v_fma_f32 v113, v113, %[ix], %[bx]\n\t"
+        "v_cvt_f32_u32_sdwa v114, v120 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+        "v_fma_f32 v114, v114, %[iy], %[ay]\n\t"
+        "v_cvt_f32_u32_sdwa v115, v122 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
+        "v_fma_f32 v115, v115, %[iy], %[by]\n\t"
+        "v_cvt_f32_u32_sdwa v116, v121 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
+        "v_fma_f32 v116, v116, %[iz], %[az]\n\t"
+        "v_cvt_f32_u32_sdwa v117, v122 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+        "v_fma_f32 v117, v117, %[iz], %[bz]\n\t"
+        "v_min_f32_e32 v118, v112, v113\n\t"
+        "v_max_f32_e32 v112, v112, v113\n\t"
+        "v_min_f32_e32 v113, v114, v115\n\t"
+        "v_max_f32_e32 v114, v114, v115\n\t"
+        "v_min_f32_e32 v115, v116, v117\n\t"
+        "v_max_f32_e32 v116, v116, v117\n\t"
+        "v_max_f32_e32 v115, 0, v115\n\t"
+        "v_min_f32_e32 v116, v116, %[tmax]\n\t"
+        "v_max3_f32 v118, v118, v113, v115\n\t"   // entry parameter of child 0
+        "v_min3_f32 v119, v112, v114, v116\n\t"   // exit parameter of child 0
+        // child 1: v123 = lo.x lo.y | v124 = lo.z hi.x | v125 = hi.y hi.z
+        "v_cvt_f32_u32_sdwa v112, v123 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
+        "v_fma_f32 v112, v112, %[ix], %[ax]\n\t"
+        "v_cvt_f32_u32_sdwa v113, v124 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+        "v_fma_f32 v113, v113, %[ix], %[bx]\n\t"
+        "v_cvt_f32_u32_sdwa v114, v123 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+        "v_fma_f32 v114, v114, %[iy], %[ay]\n\t"
+        "v_cvt_f32_u32_sdwa v115, v125 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
+        "v_fma_f32 v115, v115, %[iy], %[by]\n\t"
+        "v_cvt_f32_u32_sdwa v116, v124 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
+        "v_fma_f32 v116, v116, %[iz], %[az]\n\t"
+        "v_cvt_f32_u32_sdwa v117, v125 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+        "v_fma_f32 v117, v117, %[iz], %[bz]\n\t"
+        "v_min_f32_e32 v122, v112, v113\n\t"
+        "v_max_f32_e32 v112, v112, v113\n\t"
+        "v_min_f32_e32 v113, v114, v115\n\t"
+        "v_max_f32_e32 v114, v114, v115\n\t"
+        "v_min_f32_e32 v115, v116, v117\n\t"
+        "v_max_f32_e32 v116, v116, v117\n\t"
+        "v_max_f32_e32 v115, 0, v115\n\t"
+        "v_min_f32_e32 v116, v116, %[tmax]\n\t"
+        "v_max3_f32 v122, v122, v113, v115\n\t"   // entry parameter of child 1
+        "v_min3_f32 v120, v112, v114, v116\n\t"   // exit parameter of child 1
+        // v126, v127 = child links c0, c1
+        "v_cmp_le_f32_e64 s[90:91], v118, v119\n\t"   // h0
+        "v_cmp_le_f32_e64 s[92:93], v122, v120\n\t"   // h1
+        "v_cmp_lt_f32_e64 s[94:95], v122, v118\n\t"   // child 1 is entered first
+        "s_and_b64 s[96:97], s[90:91], s[92:93]\n\t"  // both
+        "s_or_b64 s[98:99], s[90:91], s[92:93]\n\t"   // any
+        "s_and_b64 s[94:95], s[94:95], s[92:93]\n\t"
+        "s_andn2_b64 s[94:95], s[90:91], s[94:95]\n\t"  // go to c0: h0 and not (h1 and child 1 first)
+        "s_andn2_b64 s[98:99], exec, s[98:99]\n\t"      // none
+        "v_cndmask_b32_e64 %[node], v127, v126, s[94:95]\n\t"
+        "v_cndmask_b32_e64 v112, v126, v127, s[94:95]\n\t"  // the other child, pushed where both are hit
+        "s_mov_b64 exec, s[96:97]\n\t"
+        "v_lshl_add_u32 v113, %[sp], %[shift], %[stk]\n\t"
+        "ds_write_b32 v113, %[top]\n\t"
+        "v_add_u32_e32 %[sp], 1, %[sp]\n\t"
+        "v_mov_b32_e32 %[top], v112\n\t"
+        "s_mov_b64 exec, s[98:99]\n\t"
+        "v_mov_b32_e32 %[node], %[top]\n\t"
+        "v_add_u32_e32 %[sp], -1, %[sp]\n\t"
+        "v_lshl_add_u32 v113, %[sp], %[shift], %[stk]\n\t"
+        "ds_read_b32 %[top], v113\n\t"
+        "s_mov_b64 exec, s[88:89]\n\t"
+        "s_branch 1b\n\t"
+        "2:\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        : [node] "+v"(T.node), [sp] "+v"(T.sp), [top] "+v"(T.top), [cnt] "=&s"(lanes_on_inner)
+        : [ix] "v"(T.inv[0]), [iy] "v"(T.inv[1]), [iz] "v"(T.inv[2]), [ax] "v"(T.A[0]), [ay] "v"(T.A[1]),
+          [az] "v"(T.A[2]), [bx] "v"(T.B[0]), [by] "v"(T.B[1]), [bz] "v"(T.B[2]), [tmax] "v"(T.tmax),
+          [stk] "v"(stk_addr), [base] "s"(nodes32), [thr] "s"(thr), [sentinel] "s"(kLeafSentinel),
+          [shift] "n"(kShift)
+        : "memory", "vcc", "scc", "v112", "v113", "v114", "v115", "v116", "v117",
+          "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "s88", "s89", "s90", "s91",
+          "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
+}
+
 template <bool LDS16, int BLOCK>
 __device__ __forceinline__ void leaf_step(const Tables& Tb, const Path& p, Trav& T, int32_t* stk) {
     const int32_t k = ~T.node;
@@ -1061,6 +1166,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
             const int run_threshold = max(inner_threshold, int(__popcll(__ballot(T.node >= 0))) - leave_threshold);
             if (LDS16 && !STATS) {
                 inner_loop_lds16<BLOCK>(T, q0_addr, q1_addr, stk_addr, run_threshold);
+            } else if (!STATS) {
+                inner_loop_hbm<BLOCK>(T, S.nodes32, stk_addr, run_threshold);
             } else {
                 for (;;) {
                     const int n_inner = int(__popcll(__ballot(T.node >= 0)));
