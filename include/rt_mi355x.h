@@ -198,6 +198,16 @@ int rt_finalize(const float* sum_rgb, size_t n_pixels, uint32_t spp_total, uint8
  * [0, sample_begin) of every pixel; rgb8 is then the image of all sample_end samples. */
 int rt_render(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, float* sum_rgb, uint8_t* rgb8);
 
+/* One render over several GPUs of the node from ONE process — what a host that cannot start a process per GPU
+ * (the Rust crate calling through FFI) uses in place of the per-rank path.  `scenes` are handles of the same
+ * hittables created on different devices (rt_scene_create(..., device = g, ...)); handle g traces the sample
+ * indices [begin + g*spp/G, begin + (g+1)*spp/G) of every pixel on its device, all devices at the same time; the
+ * partial sums are then copied peer to peer (xGMI) to the first handle's device and added there in handle order,
+ * and that device applies mean / gamma / quantise.  The image is that of one device tracing all samples up to f32
+ * summation order.  Host buffers as in rt_render; synchronous. */
+int rt_render_multi(rt_scene* const* scenes, size_t n_scenes, const rt_camera* cam, const rt_render_opts* opts,
+                    float* sum_rgb, uint8_t* rgb8);
+
 /* Nearest hit of n rays: what tree_filter + min_by produce for one segment
  * (src/boundingvolume.rs:214-231, src/lib.rs:94-98; the linear scan of
  * src/lib.rs:46-49 when the scene holds discs).  orig/dir: n*3 floats, dir is

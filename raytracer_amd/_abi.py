@@ -125,6 +125,7 @@ PROTOTYPES = {
     "rt_render_chunk": (_i, [C.POINTER(rt_camera), C.POINTER(rt_render_opts), C.POINTER(_u32)]),
     "rt_finalize_device": (_i, [_vp, _vp, _sz, _u32, _vp, _vp]),
     "rt_render": (_i, [_vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts), _vp, _vp]),
+    "rt_render_multi": (_i, [C.POINTER(_vp), _sz, C.POINTER(rt_camera), C.POINTER(rt_render_opts), _vp, _vp]),
     "rt_trace_primary": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     "rt_generate_primary": (_i, [_vp, C.POINTER(rt_camera), _u64, _u32, _u32, _u32, _u32, _vp, _vp]),
     "rt_trace_paths": (_i, [_vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts), _vp, _vp, _sz, _vp]),

@@ -243,6 +243,18 @@ def _path_segments(self, cam, pixel, sample, depth=REFERENCE_DEPTH, seed=0, max_
 Scene.path_segments = _path_segments
 
 
+def render_multi(scenes, cam, spp, depth=REFERENCE_DEPTH, seed=0, sample_begin=0, want_sum=True, want_rgb8=True, samples_per_item=0):
+    """One render split by sample index over the devices of `scenes` (one Scene per device, same hittables), summed
+    on the first one: returns (sum_rgb, rgb8) like Scene.render."""
+    H, W = cam.vert_res, cam.horiz_res
+    s = np.zeros((H, W, 3), dtype=np.float32) if want_sum else None
+    q = np.zeros((H, W, 3), dtype=np.uint8) if want_rgb8 else None
+    o = Scene.opts(sample_begin, sample_begin + spp, depth, seed, 0, samples_per_item)
+    handles = (C.c_void_p * len(scenes))(*[sc.handle for sc in scenes])
+    check(lib.rt_render_multi(handles, len(scenes), C.byref(cam.c), C.byref(o), ptr(s), ptr(q)))
+    return s, q
+
+
 def write_ppm(path, rgb8):
     a = np.ascontiguousarray(rgb8, dtype=np.uint8)
     check(lib.rt_write_ppm(os.fsencode(path), ptr(a), a.shape[1], a.shape[0]))

@@ -1858,6 +1858,73 @@ int rt_render(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts,
     return rc;
 }
 
+int rt_render_multi(rt_scene* const* scenes, size_t n_scenes, const rt_camera* cam, const rt_render_opts* opts, float* sum_rgb,
+                    uint8_t* rgb8) {
+    if (!scenes || n_scenes == 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_multi: no scene handles");
+    if (n_scenes > 64) return fail(RT_ERR_LIMIT, "rt_render_multi: more than 64 scene handles");
+    for (size_t g = 0; g < n_scenes; ++g) {
+        int rc = check_render_args(scenes[g], cam, opts, "rt_render_multi");
+        if (rc != RT_OK) return rc;
+    }
+    if (opts->flags & RT_RENDER_ACCUMULATE) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_multi: RT_RENDER_ACCUMULATE is not supported here");
+    const uint32_t spp = opts->sample_end - opts->sample_begin;
+    if (spp < n_scenes) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_multi: %u samples for %zu devices", spp, n_scenes);
+    const size_t n_pixels = size_t(cam->horiz_res) * cam->vert_res, bytes = n_pixels * 3 * sizeof(float);
+    std::vector<float*> d_sum(n_scenes, nullptr);
+    std::vector<hipStream_t> streams(n_scenes, nullptr);
+    float* d_tmp = nullptr;
+    uint8_t* d_rgb = nullptr;
+    int rc = RT_OK;
+    auto chk = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == RT_OK) rc = fail(RT_ERR_DEVICE, "rt_render_multi: %s failed: %s", what, hipGetErrorString(e));
+    };
+    // every device traces its share of the sample indices at the same time, each on a stream of its own
+    for (size_t g = 0; g < n_scenes && rc == RT_OK; ++g) {
+        chk(hipSetDevice(scenes[g]->device), "hipSetDevice");
+        chk(hipStreamCreateWithFlags(&streams[g], hipStreamNonBlocking), "hipStreamCreate");
+        chk(hipMalloc(reinterpret_cast<void**>(&d_sum[g]), bytes), "hipMalloc");
+        if (rc != RT_OK) break;
+        rt_render_opts o = *opts;
+        o.sample_begin = opts->sample_begin + uint32_t(uint64_t(spp) * g / n_scenes);
+        o.sample_end = opts->sample_begin + uint32_t(uint64_t(spp) * (g + 1) / n_scenes);
+        rc = rt_render_device(scenes[g], cam, &o, d_sum[g], streams[g]);
+    }
+    // the one exchange: the partial images are added on the first device, in handle order (a fixed summation order)
+    const int dev0 = scenes[0]->device;
+    if (rc == RT_OK && n_scenes > 1) {
+        chk(hipSetDevice(dev0), "hipSetDevice");
+        chk(hipMalloc(reinterpret_cast<void**>(&d_tmp), bytes), "hipMalloc");
+    }
+    for (size_t g = 1; g < n_scenes && rc == RT_OK; ++g) {
+        chk(hipSetDevice(scenes[g]->device), "hipSetDevice");
+        chk(hipStreamSynchronize(streams[g]), "render on a device");
+        chk(hipSetDevice(dev0), "hipSetDevice");
+        chk(hipMemcpyPeerAsync(d_tmp, dev0, d_sum[g], scenes[g]->device, bytes, streams[0]), "hipMemcpyPeerAsync");
+        if (rc != RT_OK) break;
+        const size_t n = n_pixels * 3;
+        hipLaunchKernelGGL(combine_kernel, dim3(uint32_t((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, streams[0], d_tmp, 1u, n, 1u, d_sum[0]);
+        chk(hipGetLastError(), "combine_kernel");
+    }
+    if (rc == RT_OK) chk(hipSetDevice(dev0), "hipSetDevice");
+    if (rc == RT_OK && rgb8) {
+        chk(hipMalloc(reinterpret_cast<void**>(&d_rgb), n_pixels * 3), "hipMalloc");
+        if (rc == RT_OK) rc = rt_finalize_device(scenes[0], d_sum[0], n_pixels, spp, d_rgb, streams[0]);
+    }
+    if (rc == RT_OK) chk(hipStreamSynchronize(streams[0]), "kernel execution");
+    if (rc == RT_OK && sum_rgb) chk(hipMemcpy(sum_rgb, d_sum[0], bytes, hipMemcpyDeviceToHost), "download");
+    if (rc == RT_OK && rgb8) chk(hipMemcpy(rgb8, d_rgb, n_pixels * 3, hipMemcpyDeviceToHost), "download");
+    for (size_t g = 0; g < n_scenes; ++g) {
+        if (hipSetDevice(scenes[g]->device) != hipSuccess) continue;
+        if (streams[g]) { (void)hipStreamSynchronize(streams[g]); (void)hipStreamDestroy(streams[g]); }
+        if (d_sum[g]) (void)hipFree(d_sum[g]);
+    }
+    if (hipSetDevice(dev0) == hipSuccess) {
+        if (d_tmp) (void)hipFree(d_tmp);
+        if (d_rgb) (void)hipFree(d_rgb);
+    }
+    return rc;
+}
+
 int rt_trace_primary(rt_scene* scene, const float* orig, const float* dir, size_t n, int32_t* id, double* t, double* normal) {
     if (!scene || !orig || !dir || !id || !t || !normal) return fail(RT_ERR_INVALID_ARGUMENT, "rt_trace_primary: null argument");
     if (n == 0) return RT_OK;

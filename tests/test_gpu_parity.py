@@ -539,3 +539,21 @@ def test_wide_spheres_outside_the_tree(rt, ob):
         for k in range(3):
             total += cols[:, k, :]
         assert np.array_equal(total.reshape(48, 64, 3), img), name
+
+
+def test_render_multi_splits_samples_over_scene_handles(rt, scene1):
+    """rt_render_multi on a one-GPU box: three handles on the same device stand in for three GPUs; the sample split,
+    the concurrent renders, the peer copies and the ordered sum are the code that runs on a real node."""
+    h = rt.gen_scene(1)
+    scenes = [scene1, rt.Scene(h), rt.Scene(h)]
+    cam = rt.default_camera(160, 96)
+    s, q = rt.render_multi(scenes, cam, 10, depth=50, seed=4)
+    parts = [scene1.render(cam, e - b, depth=50, seed=4, sample_begin=b)[0] for b, e in (rt.sample_shard(10, g, 3) for g in range(3))]
+    assert np.array_equal(s, (parts[0] + parts[1]) + parts[2])  # handle order, f32
+    whole, q_whole = scene1.render(cam, 10, depth=50, seed=4)
+    assert np.allclose(s, whole, rtol=2e-6, atol=1e-6)
+    assert np.abs(q.astype(int) - q_whole.astype(int)).max() <= 1 and (q != q_whole).mean() < 1e-3
+    one, q_one = rt.render_multi([scene1], cam, 10, depth=50, seed=4)
+    assert np.array_equal(one, whole) and np.array_equal(q_one, q_whole)
+    with pytest.raises(rt.RtError):
+        rt.render_multi(scenes, cam, 2)  # fewer samples than devices

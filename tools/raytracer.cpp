@@ -35,6 +35,7 @@ static void usage(int code) {
         "      --seed <S>                     sampler seed [default: 0]\n"
         "      --scene-seed <S>               seed of the random scene [default: 1]\n"
         "      --device <N>                   GPU index [default: 0]\n"
+        "      --gpus <G>                     split the samples over GPUs 0..G-1 of this node [default: 1]\n"
         "      --checkpoint <PATH>            keep the running sums in PATH: continue from it if it matches this\n"
         "                                     scene, frame, depth and seed, and save it after every pass\n"
         "      --every <N>                    samples per pass when --checkpoint is given [default: all]\n"
@@ -51,6 +52,7 @@ int main(int argc, char** argv) {
     std::string scene_path = "./scene.json", out_path = "./image.ppm";  // src/main.rs:26, :38
     std::string checkpoint_path;
     uint32_t every = 0;
+    int gpus = 1;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto value = [&]() -> const char* {
@@ -71,6 +73,7 @@ int main(int argc, char** argv) {
         else if (a == "--seed") seed = std::strtoull(value(), nullptr, 10);
         else if (a == "--scene-seed") scene_seed = std::strtoull(value(), nullptr, 10);
         else if (a == "--device") device = std::atoi(value());
+        else if (a == "--gpus") gpus = std::atoi(value());
         else if (a == "--checkpoint") checkpoint_path = value();
         else if (a == "--every") every = uint32_t(std::strtoul(value(), nullptr, 10));
         else if (a == "-h" || a == "--help") usage(0);
@@ -102,7 +105,22 @@ int main(int argc, char** argv) {
     std::printf("Computing with %llu samples\n", (unsigned long long)cam.horiz_res * cam.vert_res * spp);  // 64-bit, unlike src/main.rs:48
     std::fflush(stdout);
     const auto t0 = std::chrono::steady_clock::now();
-    if (checkpoint_path.empty()) {
+    if (gpus > 1) {
+        // one scene handle per device, the sample indices split among them, the sums added on the first device
+        if (!checkpoint_path.empty()) { std::fprintf(stderr, "raytracer: --checkpoint and --gpus cannot be combined\n"); return 2; }
+        std::vector<rt_scene*> scenes(size_t(gpus), nullptr);
+        for (int g = 0; g < gpus; ++g)
+            if (rt_scene_create(hittables, n, textures, n_textures, g, &scenes[size_t(g)])) die("scene");
+        std::vector<uint8_t> rgb8(size_t(cam.horiz_res) * cam.vert_res * 3, 0);
+        rt_render_opts o;
+        std::memset(&o, 0, sizeof o);
+        o.sample_end = spp;
+        o.depth = depth;
+        o.seed = seed;
+        if (rt_render_multi(scenes.data(), scenes.size(), &cam, &o, nullptr, rgb8.data())) die("render");
+        for (rt_scene* sc : scenes) rt_scene_destroy(sc);
+        if (rt_write_ppm(out_path.c_str(), rgb8.data(), cam.horiz_res, cam.vert_res)) die("image");
+    } else if (checkpoint_path.empty()) {
         // src/main.rs:35-42; unlike the reference the file is truncated, so a smaller image leaves no stale tail
         const int fd = ::open(out_path.c_str(), O_CREAT | O_WRONLY | O_TRUNC, 0644);
         if (fd < 0) {
