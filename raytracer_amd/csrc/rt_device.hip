@@ -1469,18 +1469,23 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
     if (!hittables && n_hittables) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: null hittables");
     if (!textures && n_textures) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: null textures");
     if (n_hittables > (size_t(1) << 30)) return fail(RT_ERR_LIMIT, "rt_scene_create: more than 2^30 hittables");
-    int n_dev = rt_device_count();
-    if (n_dev <= 0) return fail(RT_ERR_DEVICE, "rt_scene_create: no HIP device is visible");
-    if (device < 0 || device >= n_dev) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: device %d of %d", device, n_dev);
     auto t0 = std::chrono::steady_clock::now();
 
-    // validate and split by shape
+    // validate and split by shape (before any device work: a bad scene is reported as such on any machine)
     std::vector<uint32_t> sphere_ids, disc_ids;
     for (size_t i = 0; i < n_hittables; ++i) {
         const rt_hittable& h = hittables[i];
         if (h.shape == RT_SHAPE_SPHERE) sphere_ids.push_back(uint32_t(i));
         else if (h.shape == RT_SHAPE_DISC) disc_ids.push_back(uint32_t(i));
         else return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: hittable %zu has shape %d", i, h.shape);
+        // The reference computes on with NaN or infinite geometry and paints garbage; here the f32 descent needs finite
+        // box planes well inside the f32 range, so such a scene is refused.
+        const double lim = 1.0e15;
+        bool finite = std::isfinite(h.radius) && std::fabs(h.radius) <= lim;
+        for (int a = 0; a < 3; ++a) finite = finite && std::isfinite(h.centre[a]) && std::fabs(h.centre[a]) <= lim;
+        if (h.shape == RT_SHAPE_DISC)
+            for (int a = 0; a < 3; ++a) finite = finite && std::isfinite(h.normal[a]);
+        if (!finite) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: hittable %zu has non-finite or out-of-range (> 1e15) geometry", i);
         if (h.material < RT_MAT_DIFFUSE || h.material > RT_MAT_EMITTER)
             return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: hittable %zu has material %d", i, h.material);
         if (h.material == RT_MAT_TEXTUREMAP && (h.texture < 0 || size_t(h.texture) >= n_textures))
@@ -1489,6 +1494,10 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
     for (size_t i = 0; i < n_textures; ++i)
         if (!textures[i].rgb8 || textures[i].width == 0 || textures[i].height == 0)
             return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: texture %zu is empty", i);
+
+    int n_dev = rt_device_count();
+    if (n_dev <= 0) return fail(RT_ERR_DEVICE, "rt_scene_create: no HIP device is visible");
+    if (device < 0 || device >= n_dev) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: device %d of %d", device, n_dev);
 
     rt_scene* sc = new rt_scene;
     sc->device = device;

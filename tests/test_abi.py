@@ -135,3 +135,24 @@ def test_shapes_and_materials_helpers(rt):
     assert int(s["material"]) == 1 and s["fuzz"] == 0.1 and int(s["texture"]) == -1
     arr = rt.hittables([s, d])
     assert arr.dtype == rt.HITTABLE_DTYPE and len(arr) == 2
+
+
+def test_scene_validation_needs_no_device(rt):
+    """Bad scenes are refused before any device work, with the status that names the problem."""
+    ok = rt.sphere([0, 0, 0], 1.0, rt.diffuse([.5, .5, .5]))
+    for field, value, status in (("radius", float("nan"), 1), ("radius", float("inf"), 1), ("radius", 1e16, 1),
+                                 ("shape", 7, 2), ("material", 9, 2)):
+        h = rt.hittables([ok, ok])
+        h[1][field] = value
+        with pytest.raises(rt.RtError) as e:
+            rt.Scene(h)
+        assert e.value.status == status, (field, value, str(e.value))
+    h = rt.hittables([ok])
+    h[0]["centre"][1] = float("nan")
+    with pytest.raises(rt.RtError) as e:
+        rt.Scene(h)
+    assert e.value.status == 1 and "hittable 0" in str(e.value)
+    t = rt.hittables([rt.sphere([0, 0, 0], 1.0, rt.texture_map(3, [0, 1, 0], [1, 0, 0]))])
+    with pytest.raises(rt.RtError) as e:
+        rt.Scene(t)  # names texture 3 of 0
+    assert e.value.status == 1
