@@ -151,8 +151,8 @@ int rt_scene_create(const rt_hittable* hittables, size_t n_hittables, const rt_t
 
 /* The same with a choice of tree builder.  Both replace make_coveringtree (src/boundingvolume.rs:192-208) and
  * give the same nearest hits; they differ in build time and in how many boxes a ray visits.
- *   RT_BUILDER_SAH_HOST     binned surface-area heuristic on the host (default; 1 M spheres: ~0.9 s)
- *   RT_BUILDER_LBVH_DEVICE  Morton-order linear BVH built on the GPU (1 M spheres: milliseconds) */
+ *   RT_BUILDER_SAH_HOST     binned surface-area heuristic on the host, large subtrees on separate threads (default; 1 M spheres: ~0.4 s)
+ *   RT_BUILDER_LBVH_DEVICE  Morton-order linear BVH built on the GPU (1 M spheres: ~0.25 s with the host-side tables, slower to trace) */
 enum rt_builder { RT_BUILDER_DEFAULT = 0, RT_BUILDER_SAH_HOST = 1, RT_BUILDER_LBVH_DEVICE = 2 };
 typedef struct rt_scene_opts {
     uint32_t builder; /* rt_builder */

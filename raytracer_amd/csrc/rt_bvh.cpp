@@ -6,9 +6,16 @@
 // to differ: a leaf of the reference tree is reached iff its own box passes the
 // line test (an ancestor's per-axis interval always contains its descendants'),
 // so the nearest hit does not depend on how the boxes are grouped.
+//
+// A subtree over m spheres has exactly m - 1 inner nodes and m leaves, so the depth-first position of every node
+// and leaf is known before the subtree is built: both halves of a split write into their own index ranges, and
+// large halves are built on separate threads.  The result does not depend on the number of threads.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <future>
 #include <limits>
+#include <thread>
 
 #include "rt_internal.h"
 
@@ -58,20 +65,24 @@ struct Builder {
     std::vector<uint32_t> idx;
     uint32_t max_depth;
     BuiltBvh* out;
+    std::atomic<uint32_t> depth{0};
+    std::atomic<int> threads_left{0};  // extra threads that may still be started
+    static constexpr size_t kParallelMin = 16384;  // spheres in a subtree worth a thread of its own
 
     const double* centroid(uint32_t p) const { return sph + 4 * size_t(p); }
 
     // Returns the child reference for [begin, end) and its bounds.
-    int32_t build(size_t begin, size_t end, uint32_t level, Box* bounds) {
+    // node_base / leaf_base: where this subtree's inner nodes and leaves start in depth-first order.
+    int32_t build(size_t begin, size_t end, uint32_t level, size_t node_base, size_t leaf_base, Box* bounds) {
         const size_t m = end - begin;
         if (m == 1) {
             *bounds = prim_box[idx[begin]];
-            out->leaf_order.push_back(idx[begin]);
-            return ~int32_t(out->leaf_order.size() - 1);
+            out->leaf_order[leaf_base] = idx[begin];
+            return ~int32_t(leaf_base);
         }
-        out->depth = std::max(out->depth, level);
-        const int32_t me = int32_t(out->nodes.size());
-        out->nodes.emplace_back();
+        uint32_t seen = depth.load(std::memory_order_relaxed);
+        while (seen < level && !depth.compare_exchange_weak(seen, level, std::memory_order_relaxed)) {}
+        const int32_t me = int32_t(node_base);
 
         size_t mid = begin;
         const bool forced_median = (max_depth - level) < ceil_log2(m);  // levels left below this one
@@ -138,8 +149,18 @@ struct Builder {
             });
         }
         Box b0, b1;
-        int32_t c0 = build(begin, mid, level + 1, &b0);
-        int32_t c1 = build(mid, end, level + 1, &b1);
+        const size_t m0 = mid - begin;  // left half: m0 - 1 inner nodes right after this one, m0 leaves
+        int32_t c0, c1;
+        if (m >= kParallelMin && threads_left.fetch_sub(1, std::memory_order_relaxed) > 0) {
+            auto right = std::async(std::launch::async, [&]() { return build(mid, end, level + 1, node_base + m0, leaf_base + m0, &b1); });
+            c0 = build(begin, mid, level + 1, node_base + 1, leaf_base, &b0);
+            c1 = right.get();
+            threads_left.fetch_add(1, std::memory_order_relaxed);
+        } else {
+            if (m >= kParallelMin) threads_left.fetch_add(1, std::memory_order_relaxed);
+            c0 = build(begin, mid, level + 1, node_base + 1, leaf_base, &b0);
+            c1 = build(mid, end, level + 1, node_base + m0, leaf_base + m0, &b1);
+        }
         Node& nd = out->nodes[size_t(me)];
         for (int a = 0; a < 3; ++a) {
             nd.lo0[a] = round_down(b0.lo[a]); nd.hi0[a] = round_up(b0.hi[a]);
@@ -178,10 +199,13 @@ void build_bvh(const double* spheres, size_t n, uint32_t max_depth, BuiltBvh* ou
         scene.grow(b.prim_box[i]);
         b.idx[i] = uint32_t(i);
     }
-    out->nodes.reserve(n);
-    out->leaf_order.reserve(n);
+    out->nodes.assign(n > 1 ? n - 1 : 0, Node());
+    out->leaf_order.assign(n, 0);
+    const unsigned hw = std::thread::hardware_concurrency();
+    b.threads_left = int(std::min<unsigned>(hw ? hw : 1u, 16u)) - 1;
     Box root;
-    int32_t ref = b.build(0, n, 1, &root);
+    int32_t ref = b.build(0, n, 1, 0, 0, &root);
+    out->depth = b.depth.load();
     if (ref < 0) {
         // a single sphere: the root's second child is the same leaf behind a far-away point box
         // (entering it would only repeat the same sphere test)
