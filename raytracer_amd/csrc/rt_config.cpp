@@ -10,6 +10,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <new>
 #include <string>
 #include <utility>
 #include <vector>
@@ -444,7 +445,11 @@ extern "C" {
 int rt_config_parse(const char* json, size_t len, const char* texture_dir, rt_config** out) {
     if (!json || !out) return rt::fail(RT_ERR_INVALID_ARGUMENT, "rt_config_parse: null argument");
     *out = nullptr;
-    return rt::parse_config(json, len, texture_dir, out);
+    try {
+        return rt::parse_config(json, len, texture_dir, out);
+    } catch (const std::bad_alloc&) {  // nothing may unwind across the C boundary
+        return rt::fail(RT_ERR_LIMIT, "rt_config_parse: out of memory");
+    }
 }
 
 int rt_config_load(const char* path, rt_config** out) {
@@ -460,7 +465,7 @@ int rt_config_load(const char* path, rt_config** out) {
     std::string dir(path);
     const size_t slash = dir.find_last_of('/');
     dir = slash == std::string::npos ? std::string() : dir.substr(0, slash);
-    return rt::parse_config(text.data(), text.size(), dir.c_str(), out);
+    return rt_config_parse(text.data(), text.size(), dir.c_str(), out);
 }
 
 void rt_config_destroy(rt_config* cfg) { delete cfg; }

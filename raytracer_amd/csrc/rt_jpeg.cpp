@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "rt_internal.h"
@@ -46,7 +47,7 @@ struct Component {
     int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0;
     int blocks_w = 0, blocks_h = 0;  // allocated block grid (whole MCUs)
     int stride = 0;
-    int pred = 0;
+    int64_t pred = 0;
     std::vector<uint8_t> plane;
 };
 
@@ -156,6 +157,7 @@ struct Decoder {
         width = u16();
         ncomp = u8();
         if (width <= 0 || height <= 0) return fail("empty image");
+        if (int64_t(width) * height > (int64_t(1) << 28)) return fail("image larger than 2^28 pixels");
         if (ncomp != 1 && ncomp != 3) return fail("only 1- or 3-component images are supported");
         for (int i = 0; i < ncomp; ++i) {
             comp[i].id = u8();
@@ -180,19 +182,20 @@ struct Decoder {
     }
 
     // jidctint.c "islow": two passes of the LL&M butterfly over dequantised coefficients.
-    static inline int32_t descale(int32_t x, int n) { return (x + (int32_t(1) << (n - 1))) >> n; }
-    static void idct_pass(const int32_t in[8], int32_t out[8], int shift) {
-        const int32_t F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633,
+    // 64-bit like IJG's JLONG: valid streams stay far inside 32 bits, damaged ones must not overflow
+    static inline int64_t descale(int64_t x, int n) { return (x + (int64_t(1) << (n - 1))) >> n; }
+    static void idct_pass(const int64_t in[8], int64_t out[8], int shift) {
+        const int64_t F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633,
                       F1_501 = 12299, F1_847 = 15137, F1_961 = 16069, F2_053 = 16819, F2_562 = 20995, F3_072 = 25172;
-        int32_t z2 = in[2], z3 = in[6];
-        int32_t z1 = (z2 + z3) * F0_541;
-        int32_t tmp2 = z1 + z3 * (-F1_847);
-        int32_t tmp3 = z1 + z2 * F0_765;
+        int64_t z2 = in[2], z3 = in[6];
+        int64_t z1 = (z2 + z3) * F0_541;
+        int64_t tmp2 = z1 + z3 * (-F1_847);
+        int64_t tmp3 = z1 + z2 * F0_765;
         z2 = in[0];
         z3 = in[4];
-        int32_t tmp0 = (z2 + z3) * 8192;
-        int32_t tmp1 = (z2 - z3) * 8192;
-        const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        int64_t tmp0 = (z2 + z3) * 8192;
+        int64_t tmp1 = (z2 - z3) * 8192;
+        const int64_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
         tmp0 = in[7];
         tmp1 = in[5];
         tmp2 = in[3];
@@ -200,8 +203,8 @@ struct Decoder {
         z1 = tmp0 + tmp3;
         z2 = tmp1 + tmp2;
         z3 = tmp0 + tmp2;
-        int32_t z4 = tmp1 + tmp3;
-        const int32_t z5 = (z3 + z4) * F1_175;
+        int64_t z4 = tmp1 + tmp3;
+        const int64_t z5 = (z3 + z4) * F1_175;
         tmp0 *= F0_298;
         tmp1 *= F2_053;
         tmp2 *= F3_072;
@@ -225,33 +228,33 @@ struct Decoder {
         out[3] = descale(tmp13 + tmp0, shift);
         out[4] = descale(tmp13 - tmp0, shift);
     }
-    static void idct_block(const int32_t coef[64], uint8_t* dst, int stride) {
-        int32_t ws[64];
+    static void idct_block(const int64_t coef[64], uint8_t* dst, int stride) {
+        int64_t ws[64];
         for (int c = 0; c < 8; ++c) {  // pass 1: columns, results scaled up by 2 bits
-            int32_t in[8], out[8];
+            int64_t in[8], out[8];
             for (int r = 0; r < 8; ++r) in[r] = coef[r * 8 + c];
             idct_pass(in, out, 13 - 2);
             for (int r = 0; r < 8; ++r) ws[r * 8 + c] = out[r];
         }
         for (int r = 0; r < 8; ++r) {  // pass 2: rows, remove the scaling and the factor 8 of the 2-D transform
-            int32_t out[8];
+            int64_t out[8];
             idct_pass(ws + r * 8, out, 13 + 2 + 3);
             for (int c = 0; c < 8; ++c) {
-                int32_t v = out[c] + 128;
+                const int64_t v = out[c] + 128;
                 dst[r * stride + c] = uint8_t(v < 0 ? 0 : (v > 255 ? 255 : v));
             }
         }
     }
 
     bool decode_block(Component& c, int bx, int by) {
-        int32_t coef[64];
+        int64_t coef[64];
         std::memset(coef, 0, sizeof coef);
         const uint16_t* q = quant[c.tq];
         int s = decode_symbol(dc[c.td]);
         if (s > 11) return fail("bad DC difference");
         int diff = s ? extend(get_bits(s), s) : 0;
         c.pred += diff;
-        coef[0] = c.pred * q[0];
+        coef[0] = c.pred * int64_t(q[0]);
         const Huff& h = ac[c.ta];
         for (int k = 1; k < 64;) {
             int rs = decode_symbol(h);
@@ -264,7 +267,7 @@ struct Decoder {
             }
             k += r;
             if (k > 63) return fail("AC coefficient index out of range");
-            coef[kZigzag[k]] = extend(get_bits(s), s) * q[k];
+            coef[kZigzag[k]] = int64_t(extend(get_bits(s), s)) * int64_t(q[k]);
             ++k;
         }
         if (error) return false;
@@ -436,11 +439,18 @@ extern "C" {
 int rt_decode_jpeg(const uint8_t* bytes, size_t len, uint8_t** rgb8, uint32_t* width, uint32_t* height) {
     if (!bytes || !rgb8 || !width || !height) return rt::fail(RT_ERR_INVALID_ARGUMENT, "rt_decode_jpeg: null argument");
     *rgb8 = nullptr;
-    rt::Decoder* d = new rt::Decoder();
+    rt::Decoder* d = new (std::nothrow) rt::Decoder();
+    if (!d) return rt::fail(RT_ERR_LIMIT, "rt_decode_jpeg: out of memory");
     d->data = bytes;
     d->len = len;
     std::memset(d->quant, 0, sizeof d->quant);
-    if (!d->run()) {
+    bool ok = false;
+    try {
+        ok = d->run();
+    } catch (const std::bad_alloc&) {  // nothing may unwind across the C boundary
+        d->fail("out of memory");
+    }
+    if (!ok) {
         int rc = rt::fail(RT_ERR_UNSUPPORTED, "cannot open file: JPEG decode failed: %s", d->error ? d->error : "?");
         delete d;
         return rc;

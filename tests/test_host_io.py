@@ -279,3 +279,32 @@ def test_resumed_render_equals_uninterrupted(rt, tmp_path):
     assert np.array_equal(_read_ppm(a), q_whole.reshape(64, 96, 3))
     other = subprocess.run(args[:-1] + ["6", "-s", "12", "--out", str(b), "--checkpoint", str(ck)], capture_output=True, text=True, timeout=120)
     assert other.returncode == 101 and "another scene, frame, depth or seed" in other.stderr
+
+
+def test_jpeg_decoder_survives_damaged_files(rt):
+    """Bit flips, truncation and garbage never crash the decoder: it returns an image or an error."""
+    rng = np.random.default_rng(9)
+    good, _ = _jpeg(_picture(48, 40), quality=85, subsampling=0, restart_marker_blocks=3)
+    sub, _ = _jpeg(_picture(48, 40), quality=70, subsampling=2)
+    outcomes = {"image": 0, "error": 0}
+    for base in (good, sub):
+        for trial in range(400):
+            raw = bytearray(base)
+            for _ in range(int(rng.integers(1, 6))):
+                pos = int(rng.integers(2, len(raw)))
+                raw[pos] = int(rng.integers(0, 256))
+            if trial % 5 == 0:
+                raw = raw[: int(rng.integers(4, len(raw)))]
+            try:
+                img = rt.decode_jpeg(bytes(raw))
+                assert img.ndim == 3 and img.shape[2] == 3 and img.size > 0
+                outcomes["image"] += 1
+            except rt.RtError as e:
+                assert e.status in (2, 5)
+                outcomes["error"] += 1
+    assert outcomes["image"] > 50 and outcomes["error"] > 50, outcomes
+    huge = bytearray(good)
+    i = huge.index(b"\xff\xc0")
+    huge[i + 5 : i + 9] = b"\xff\xff\xff\xff"  # 65535 x 65535
+    with pytest.raises(rt.RtError):
+        rt.decode_jpeg(bytes(huge))
