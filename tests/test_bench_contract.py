@@ -1,0 +1,34 @@
+"""bench.py prints ONE JSON line with the agreed keys (checked on the GPU box; the values are not judged here)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.mark.gpu
+def test_bench_line_has_the_agreed_shape():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--cpu-seconds", "1"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "Mpaths/s" and d["n_gpus"] == 1 and d["steps"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and "workload" in d["config"]
+    assert abs(d["value"] - d["config"]["paths_per_step"] / d["ms_per_step"] / 1e3) < 0.01 * d["value"]
+    ro = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in ro, key
+    assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-4 and 0.02 < ro["frac"] < 1.0
+    cb = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cb, key
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    assert d["value"] > 100 * cb["value"]  # sanity: three orders of magnitude are expected, two must be there
