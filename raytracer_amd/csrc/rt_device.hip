@@ -382,7 +382,11 @@ __device__ __forceinline__ void texture_albedo(const SceneDev& S, int32_t texmat
     // Rust `as u32`: saturating, NaN -> 0
     uint32_t col = (colf > 0.0f) ? (colf >= 4294967040.0f ? 4294967295u : uint32_t(colf)) : 0u;
     uint32_t row = (rowf > 0.0f) ? (rowf >= 4294967040.0f ? 4294967295u : uint32_t(rowf)) : 0u;
-    const uchar4 px = img.px[size_t(row % img.h) * img.w + (col % img.w)];
+    // row <= h and col <= w for any finite direction (lat in [0, pi], lon in [0, 2 pi]); the remainder is only
+    // computed where it can change something, an integer division is ~25 instructions
+    if (row >= img.h) row %= img.h;
+    if (col >= img.w) col %= img.w;
+    const uchar4 px = img.px[size_t(row) * img.w + col];
     *r = float(px.x) * (1.0f / 255.0f);
     *g = float(px.y) * (1.0f / 255.0f);
     *b = float(px.z) * (1.0f / 255.0f);
