@@ -132,7 +132,8 @@ int rt_gen_scene(uint64_t seed, rt_hittable* out, size_t cap, size_t* n) {
 
 int rt_gen_scene_grid(uint64_t seed, uint32_t side, rt_hittable* out, size_t cap, size_t* n) {
     if (!n) return fail(RT_ERR_INVALID_ARGUMENT, "rt_gen_scene_grid: null count pointer");
-    if (side == 0 || side > 4096) return fail(RT_ERR_LIMIT, "rt_gen_scene_grid: side %u outside 1..4096", side);
+    // pitch 0.5: beyond side 2800 the corners of the grid would leave the ground sphere (radius 1000)
+    if (side == 0 || side > 2800) return fail(RT_ERR_LIMIT, "rt_gen_scene_grid: side %u outside 1..2800", side);
     const size_t total = size_t(side) * side + 1;
     *n = total;
     if (!out) return RT_OK;

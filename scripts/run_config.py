@@ -4,7 +4,7 @@
     python scripts/run_config.py c1|c2|c2d10|c3|c4|c5 [--spp N] [--stats]
 
 c1 bundled scene.json 512x512 (disc + emitter + texture, linear path)   c2 random spheres 1080p depth 50
-c2d10 the same at the reference's depth 10    c3 one GPU's share (125 of 1000 spp) of the same scene at 3840x2160    c4 earth + nested glass shells    c5 1M spheres 1080p 64 spp
+c2d10 the same at the reference's depth 10    c3 one GPU's share (125 of 1000 spp) of the same scene at 3840x2160    c4 earth + nested glass shells    c5 1M spheres 1080p 64 spp    c6 7.8M spheres (scene larger than the Infinity Cache) 1080p 16 spp
 """
 import argparse
 import json
@@ -46,6 +46,9 @@ def main():
     elif a.config == "c5":
         h, tex, spp, depth = rt.gen_scene_grid(1, 1000), [], 64, 50
         cam = rt.Camera.build([0, 0, 0], [130, 40, 30], 1.0, 0.1, 1920, 1080)
+    elif a.config == "c6":  # beyond the 256 MB Infinity Cache: 7.84 M spheres, 0.7 GB touched per frame, rays gather from HBM
+        h, tex, spp, depth = rt.gen_scene_grid(1, 2800), [], 16, 50
+        cam = rt.Camera.build([0, 0, 0], [360, 110, 80], 1.0, 0.1, 1920, 1080)
     elif a.config == "c1":
         cfg = rt.Config.from_json(os.path.join(ROOT, "tests", "golden", "scene.json"))
         h, tex, cam, spp, depth = cfg.hittables, cfg.textures, cfg.camera, 10, 10
