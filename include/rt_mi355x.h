@@ -136,7 +136,7 @@ int rt_default_camera(uint32_t horiz_res, uint32_t vert_res, rt_camera* out);
 int rt_gen_scene(uint64_t seed, rt_hittable* out, size_t cap, size_t* n);
 
 /* Build-defined stress scenes made only of the reference's shapes and materials.
- * grid: ground sphere + side*side small spheres (r = 0.2) resting on it, the
+ * grid: ground sphere + side*side small spheres (r = 0.2, pitch 0.5, side <= 2800) resting on it, the
  * material mix of gen_scene.  shells: the scene.json earth sphere (texture 0) +
  * `shells` concentric dielectric spheres with alternating index 1.5 / (1/1.5). */
 int rt_gen_scene_grid(uint64_t seed, uint32_t side, rt_hittable* out, size_t cap, size_t* n);
