@@ -1099,8 +1099,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     bool have_pixel = false, alive = false, done = false;
     uint32_t next_sample = 0, item_end = 0, chunk = 0, pix_xy = 0;
     float ar = 0.0f, ag = 0.0f, ab = 0.0f;
-    const int trav_threshold = int(P.trav_threshold);
-    const int inner_threshold = max(int(P.inner_threshold), 1);  // at least 1: with 0 the inner loop would never see "no lane left"
+    const int trav_threshold = int(P.trav_threshold), inner_threshold = int(P.inner_threshold);
     const int leave_threshold = int(P.leave_threshold);
     const uint32_t q0_addr = lds_address(lds_q0), q1_addr = lds_address(lds_q1), stk_addr = lds_address(stk);
 
