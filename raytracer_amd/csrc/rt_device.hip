@@ -841,6 +841,11 @@ __device__ __forceinline__ void inner_loop_lds16(Trav& T, uint32_t q0_addr, uint
                                                  int32_t thr) {
     static_assert(BLOCK == 512 || BLOCK == 256, "stack column stride");
     constexpr int kShift = (BLOCK == 512) ? 11 : 10;  // log2(BLOCK * sizeof(int32_t))
+    // the "s" operands must BE scalar registers: the constraint alone does not move a value the compiler holds in a
+    // vector register (it would print v13 into an s_ instruction)
+    thr = __builtin_amdgcn_readfirstlane(max(thr, 1));  // with 0 the loop would never see "no lane left"
+    q0_addr = uint32_t(__builtin_amdgcn_readfirstlane(int32_t(q0_addr)));
+    q1_addr = uint32_t(__builtin_amdgcn_readfirstlane(int32_t(q1_addr)));
     int32_t lanes_on_inner;
     asm volatile(
         "1:\n\t"
@@ -935,6 +940,11 @@ template <int BLOCK>
 __device__ __forceinline__ void inner_loop_hbm(Trav& T, const Node32* nodes32, uint32_t stk_addr, int32_t thr) {
     static_assert(BLOCK == 512 || BLOCK == 256, "stack column stride");
     constexpr int kShift = (BLOCK == 512) ? 11 : 10;  // log2(BLOCK * sizeof(int32_t))
+    // scalar registers for the "s" operands, as in inner_loop_lds16
+    thr = __builtin_amdgcn_readfirstlane(max(thr, 1));
+    const uint64_t base_bits = reinterpret_cast<uint64_t>(nodes32);
+    const uint64_t base = uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int32_t(uint32_t(base_bits))))) |
+                          (uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int32_t(uint32_t(base_bits >> 32))))) << 32);
     int32_t lanes_on_inner;
     asm volatile(
         "1:\n\t"
@@ -1027,7 +1037,7 @@ __device__ __forceinline__ void inner_loop_hbm(Trav& T, const Node32* nodes32, u
         : [node] "+v"(T.node), [sp] "+v"(T.sp), [top] "+v"(T.top), [cnt] "=&s"(lanes_on_inner)
         : [ix] "v"(T.inv[0]), [iy] "v"(T.inv[1]), [iz] "v"(T.inv[2]), [ax] "v"(T.A[0]), [ay] "v"(T.A[1]),
           [az] "v"(T.A[2]), [bx] "v"(T.B[0]), [by] "v"(T.B[1]), [bz] "v"(T.B[2]), [tmax] "v"(T.tmax),
-          [stk] "v"(stk_addr), [base] "s"(nodes32), [thr] "s"(thr), [sentinel] "s"(kLeafSentinel),
+          [stk] "v"(stk_addr), [base] "s"(base), [thr] "s"(thr), [sentinel] "s"(kLeafSentinel),
           [shift] "n"(kShift)
         : "memory", "vcc", "scc", "v112", "v113", "v114", "v115", "v116", "v117",
           "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "s88", "s89", "s90", "s91",
