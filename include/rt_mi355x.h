@@ -9,7 +9,10 @@
  * reference signals the same conditions with panics.  rt_last_error() gives the
  * message of the calling thread's last failure.
  *
- * A scene handle is not thread-safe: one call at a time per handle.
+ * A scene handle is not thread-safe: one call at a time per handle.  Renders of one handle also run one at a
+ * time on the device, whatever streams they are given (they share the handle's work counter and partial sums:
+ * each render waits for the handle's previous one).  Every entry point leaves the calling thread's current HIP
+ * device as it found it.
  */
 #ifndef RT_MI355X_H
 #define RT_MI355X_H
@@ -112,7 +115,8 @@ enum {
     RT_RENDER_ACCUMULATE = 1,          /* add to the buffer instead of overwriting it */
     RT_RENDER_KERNEL_LOCKSTEP = 2,     /* measurement aid: the plain one-segment-per-turn kernel */
     RT_RENDER_KERNEL_NO_LDS_SCENE = 4, /* measurement aid: keep the BVH in HBM even when it would fit in LDS */
-    RT_RENDER_STATS = 8                /* measurement aid: instrumented kernel, see rt_debug_render_stats */
+    RT_RENDER_STATS = 8,               /* measurement aid: instrumented kernel, see rt_debug_render_stats */
+    RT_RENDER_TIMING = 16              /* measurement aid: production kernel with a cycle stamp around each phase */
 };
 
 const char* rt_last_error(void);
@@ -168,14 +172,29 @@ int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out);
  * per-pixel SUM of the path colours, 3 floats per pixel, row-major with row 0 at
  * the top (src/lib.rs:166-167), in d_sum_rgb — DEVICE memory of the scene's
  * device.  `stream` is a hipStream_t (NULL = default stream); the call is
- * asynchronous with respect to the host. */
+ * asynchronous with respect to the host: it enqueues and returns.  The one
+ * exception: a render in chunks (rt_render_chunk) whose partial sums do not fit
+ * the scene's buffer waits for the handle's previous render and grows the buffer
+ * first; rt_scene_reserve does that ahead of time. */
 int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, float* d_sum_rgb,
                      void* stream);
 
+/* Sizes the scene's partial-sum buffer for renders of this frame and sample range (and anything smaller), so that
+ * rt_render_device neither allocates nor waits.  No counterpart in the reference (it has no device). */
+int rt_scene_reserve(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts);
+
 /* Measurement aid: phase counters of the last RT_RENDER_STATS render on this scene:
  * {inner-node turns*64, lanes in them, leaf turns*64, lanes, shade turns*64, lanes shading or
- * regenerating, lanes regenerating, descent-loop turns*64}.  Synchronises the device. */
+ * regenerating, lanes regenerating, descent-loop turns*64}; after an RT_RENDER_TIMING render the same
+ * words hold {shade, descent-loop header, inner loop, leaf turn, whole kernel} wave cycles summed over
+ * waves, the number of waves, 0, 0.  Synchronises the device. */
 int rt_debug_render_stats(rt_scene* scene, uint64_t out[8]);
+
+/* Parity aid: the render kernel itself (the production code, assembly loops included, built with one extra
+ * store per path) renders samples [sample_begin, sample_end) of every pixel and returns the colour of each
+ * path, rgb[(pixel * spp + sample - sample_begin) * 3 ..] — what accel_raytrace (src/lib.rs:88-135) returns
+ * for that camera ray.  Host buffer of horiz_res * vert_res * spp * 3 floats; synchronous. */
+int rt_debug_render_paths(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, float* rgb);
 
 /* Measurement aid: how rt_render_device launches its kernel for this scene on this device: threads per workgroup,
  * workgroups the runtime can keep resident per CU (registers and LDS), and the waves per SIMD that follow. */
@@ -202,9 +221,11 @@ int rt_render(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts,
  * (the Rust crate calling through FFI) uses in place of the per-rank path.  `scenes` are handles of the same
  * hittables created on different devices (rt_scene_create(..., device = g, ...)); handle g traces the sample
  * indices [begin + g*spp/G, begin + (g+1)*spp/G) of every pixel on its device, all devices at the same time; the
- * partial sums are then copied peer to peer (xGMI) to the first handle's device and added there in handle order,
- * and that device applies mean / gamma / quantise.  The image is that of one device tracing all samples up to f32
- * summation order.  Host buffers as in rt_render; synchronous. */
+ * partial sums then meet on the first handle's device, which applies mean / gamma / quantise: by one RCCL
+ * ncclReduce(sum) over xGMI when every handle sits on a different device (librccl.so is bound at the first such
+ * call), else — or with RT_MULTI_REDUCE=peer in the environment — by peer-to-peer copies, all in flight at once,
+ * into landing slots on the first device that one kernel adds in handle order.  The image is that of one device
+ * tracing all samples up to f32 summation order.  Host buffers as in rt_render; synchronous. */
 int rt_render_multi(rt_scene* const* scenes, size_t n_scenes, const rt_camera* cam, const rt_render_opts* opts,
                     float* sum_rgb, uint8_t* rgb8);
 

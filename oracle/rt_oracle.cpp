@@ -36,6 +36,8 @@ long orc_scene_build_tree(orc_scene* s) {
 }
 int orc_scene_tree_depth(const orc_scene* s) { return tree_depth(s->sc.tree.get()); }
 void orc_scene_set_tie_rule(orc_scene* s, int lowest_index) { s->sc.tie_lowest_index = lowest_index != 0; }
+// Test aid: see Scene::dir_noise (0 = the reference's behaviour).
+void orc_scene_set_dir_noise(orc_scene* s, double amplitude) { s->sc.dir_noise = amplitude; }
 
 void orc_camera_build(const double lookat[3], const double lookfrom[3], double inv_focal_length, double aperture,
                       uint32_t horiz_res, uint32_t vert_res, Camera* out) {

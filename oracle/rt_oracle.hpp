@@ -523,6 +523,10 @@ struct Scene {
     std::unique_ptr<CoveringTree> tree;  // built on demand, spheres only (boundingvolume.rs:254-256)
     size_t tree_nodes = 0;
     bool tie_lowest_index = true;
+    // Test aid, 0 = off: every ray direction (camera ray and scattered rays) is moved by up to this much per
+    // component before it is traced.  Running the same paths with and without it shows how far an error of that
+    // size in a direction — what an f32 evaluation of the same formulas commits — drifts along a path.
+    double dir_noise = 0.0;
 };
 
 inline size_t count_nodes(const CoveringTree* t) { return t ? 1 + count_nodes(t->left.get()) + count_nodes(t->right.get()) : 0; }
@@ -572,6 +576,13 @@ inline Color trace(const Scene& sc, int traverse, Ray ray, uint32_t depth, Sampl
                    TraceCounters* ctr, SegmentLog* log = nullptr) {
     Color color{1.0, 1.0, 1.0};
     for (uint32_t bounce = 1; bounce <= depth; ++bounce) {
+        if (sc.dir_noise > 0.0) {  // not part of the reference: see Scene::dir_noise
+            uint32_t c4[4] = {s.pixel, s.sample, bounce, 0x4e4f4953u}, o4[4];
+            philox4x32_10(c4, s.key, o4);
+            Vec3 d = ray.dir;
+            for (int i = 0; i < 3; ++i) d[i] += sc.dir_noise * (2.0 * (double(o4[i] >> 8) * (1.0 / 16777216.0)) - 1.0);
+            ray = Ray::make(ray.orig, d);
+        }
         candidates(sc, traverse, ray, scratch, ctr);
         if (ctr) ctr->segments++;
         int idx = -1; double t = 0.0;

@@ -18,7 +18,7 @@ RT_ERR_INVALID_ARGUMENT, RT_ERR_UNSUPPORTED, RT_ERR_DEVICE, RT_ERR_IO, RT_ERR_LI
 RT_SHAPE_SPHERE, RT_SHAPE_DISC = 0, 1
 RT_MAT_DIFFUSE, RT_MAT_METAL, RT_MAT_DIELECTRIC, RT_MAT_TEXTUREMAP, RT_MAT_EMITTER = 0, 1, 2, 3, 4
 RT_RENDER_ACCUMULATE, RT_RENDER_KERNEL_LOCKSTEP, RT_RENDER_KERNEL_NO_LDS_SCENE = 1, 2, 4
-RT_RENDER_STATS = 8
+RT_RENDER_STATS, RT_RENDER_TIMING = 8, 16
 
 # rt_hittable as a numpy record (same layout as the C struct), so that a million
 # hittables are one array and not a million Python objects.
@@ -120,7 +120,9 @@ PROTOTYPES = {
     "rt_scene_destroy": (None, [_vp]),
     "rt_scene_get_info": (_i, [_vp, C.POINTER(rt_scene_info)]),
     "rt_render_device": (_i, [_vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts), _vp, _vp]),
+    "rt_scene_reserve": (_i, [_vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts)]),
     "rt_debug_render_stats": (_i, [_vp, _vp]),
+    "rt_debug_render_paths": (_i, [_vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts), _vp]),
     "rt_debug_render_launch": (_i, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "rt_render_chunk": (_i, [C.POINTER(rt_camera), C.POINTER(rt_render_opts), C.POINTER(_u32)]),
     "rt_finalize_device": (_i, [_vp, _vp, _sz, _u32, _vp, _vp]),

@@ -192,6 +192,19 @@ class Scene:
         o = self.opts(sample_begin, sample_end, depth, seed, flags | (_abi.RT_RENDER_ACCUMULATE if accumulate else 0), samples_per_item)
         check(lib.rt_render_device(self.handle, C.byref(cam.c), C.byref(o), C.c_void_p(d_sum_ptr), C.c_void_p(stream or 0)))
 
+    def reserve(self, cam, spp, sample_begin=0, samples_per_item=0):
+        """Sizes the partial-sum buffer ahead of time, so that render_device only enqueues."""
+        o = self.opts(sample_begin, sample_begin + spp, 1, 0, 0, samples_per_item)
+        check(lib.rt_scene_reserve(self.handle, C.byref(cam.c), C.byref(o)))
+
+    def render_paths(self, cam, spp, depth=REFERENCE_DEPTH, seed=0, sample_begin=0, flags=0, samples_per_item=0):
+        """Colour of every path of a render, from the render kernel itself: float32 (H*W, spp, 3)."""
+        n = cam.vert_res * cam.horiz_res
+        rgb = np.zeros((n, spp, 3), dtype=np.float32)
+        o = self.opts(sample_begin, sample_begin + spp, depth, seed, flags, samples_per_item)
+        check(lib.rt_debug_render_paths(self.handle, C.byref(cam.c), C.byref(o), ptr(rgb)))
+        return rgb
+
     def finalize_device(self, d_sum_ptr, n_pixels, spp_total, d_rgb8_ptr, stream=None):
         check(lib.rt_finalize_device(self.handle, C.c_void_p(d_sum_ptr), int(n_pixels), int(spp_total),
                                      C.c_void_p(d_rgb8_ptr), C.c_void_p(stream or 0)))

@@ -192,9 +192,13 @@ void build_bvh(const double* spheres, size_t n, uint32_t max_depth, BuiltBvh* ou
     scene.reset();
     for (size_t i = 0; i < n; ++i) {
         const double* s = spheres + 4 * i;
-        for (int a = 0; a < 3; ++a) {  // src/boundingvolume.rs:246-248
-            b.prim_box[i].lo[a] = s[a] - s[3];
-            b.prim_box[i].hi[a] = s[a] + s[3];
+        // src/boundingvolume.rs:246-248 with |r|: a sphere given with a negative radius (the hollow-glass idiom:
+        // same surface, inward normal) occupies the same box; taken as given its box would be inside out and no
+        // parent would cover it
+        const double r = std::fabs(s[3]);
+        for (int a = 0; a < 3; ++a) {
+            b.prim_box[i].lo[a] = s[a] - r;
+            b.prim_box[i].hi[a] = s[a] + r;
         }
         scene.grow(b.prim_box[i]);
         b.idx[i] = uint32_t(i);

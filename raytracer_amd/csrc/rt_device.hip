@@ -12,11 +12,14 @@
 //     dumps) produces the same bits whatever code surrounds it.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "rt_internal.h"
 
@@ -548,46 +551,50 @@ __device__ __forceinline__ void flush_item(const RenderParams& P, float* sum_rgb
 // microsecond).  ws = this wave's four LDS words {item, next undealt pixel of its tile, tile origin x | y << 16, chunk}; called by the
 // lanes that need work.  Chunks keep the items small enough to balance the end of the launch: with one
 // item per pixel and 100 samples each, a third of the launch was spent waiting for the last items.
-__device__ __forceinline__ void claim_pixels(bool& need, bool& done, uint32_t& pixel, uint32_t& xy, uint32_t& chunk, volatile uint32_t* ws,
+// The four words are wave-uniform: they are read once into scalar registers, updated there and written back once.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return uint32_t(__builtin_amdgcn_readfirstlane(int32_t(v))); }
+
+__device__ __forceinline__ void claim_pixels(bool& need, bool& done, uint32_t& pixel, uint32_t& xy, uint32_t& chunk, lds_u32* ws,
                                              uint32_t* work_counter, const RenderParams& P, const CamDev& C) {
     const uint32_t n_items = P.tiles_x * P.tiles_y * P.n_chunks;
     const uint32_t lane = __lane_id();
     unsigned long long m = __ballot(need);
+    if (m == 0) return;
+    uint32_t item = uniform(ws[0]), next = uniform(ws[1]), origin = uniform(ws[2]), item_chunk = uniform(ws[3]);
     while (m) {
-        uint32_t item = ws[0], next = ws[1];
         if (next >= 64u) {  // the tile is dealt out: draw the next item and decode it once for its 64 pixels
             const int first = __ffsll((long long)m) - 1;
             uint32_t w = 0;
             if (int(lane) == first) w = atomicAdd(work_counter, 1u);
-            item = uint32_t(__shfl(int(w), first));
+            item = uint32_t(__builtin_amdgcn_readlane(int32_t(w), first));
             next = 0;
             if (item < n_items) {
                 const uint32_t tile = item / P.n_chunks;
                 const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
-                ws[2] = (tx * 8u) | ((ty * 8u) << 16);
-                ws[3] = item - tile * P.n_chunks;
+                origin = (tx * 8u) | ((ty * 8u) << 16);
+                item_chunk = item - tile * P.n_chunks;
             }
         }
         if (item >= n_items) {  // nothing left: remember it, so later calls cost no atomic
             if (need) { done = true; need = false; }
-            ws[0] = 0xffffffffu;
-            ws[1] = 0;
+            item = 0xffffffffu;
+            next = 0;
             break;
         }
         const uint32_t rank = uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
         const uint32_t avail = 64u - next;
         if (need && rank < avail) {
             const uint32_t in_tile = next + rank;  // row-major inside the tile
-            const uint32_t origin = ws[2];
             const uint32_t x = (origin & 0xffffu) + (in_tile & 7u);
             const uint32_t y = (origin >> 16) + (in_tile >> 3);
-            if (x < C.W && y < C.H) { pixel = y * C.W + x; xy = x | (y << 16); chunk = ws[3]; need = false; }  // outside the frame: ask again
+            if (x < C.W && y < C.H) { pixel = y * C.W + x; xy = x | (y << 16); chunk = item_chunk; need = false; }  // outside the frame: ask again
         }
         const uint32_t asked = uint32_t(__popcll(m));
-        ws[0] = item;
-        ws[1] = next + (asked < avail ? asked : avail);
+        next += asked < avail ? asked : avail;
         m = __ballot(need);
     }
+    ws[0] = item; ws[1] = next; ws[2] = origin; ws[3] = item_chunk;
 }
 
 // ---------------------------------------------------------------- kernels
@@ -601,8 +608,8 @@ __global__ __launch_bounds__(kBlock) void render_kernel(SceneDev S, CamDev C, Re
                                                         uint32_t* __restrict__ work_counter) {
     extern __shared__ int32_t stack_lds[];
     int32_t* stk = stack_lds + threadIdx.x;
-    volatile uint32_t* wave_state = reinterpret_cast<uint32_t*>(stack_lds + stack_depth * kBlock) + 4 * (threadIdx.x >> 6);
-    if ((threadIdx.x & 63) == 0) { wave_state[0] = 0; wave_state[1] = 64; }
+    lds_u32* wave_state = (lds_u32*)(reinterpret_cast<uint32_t*>(stack_lds + stack_depth * kBlock) + 4 * (threadIdx.x >> 6));
+    wave_state[0] = 0; wave_state[1] = 64; wave_state[2] = 0; wave_state[3] = 0;
 
     Path p;
     p.ox = p.oy = p.oz = 0.0;
@@ -1052,15 +1059,36 @@ __device__ __forceinline__ void leaf_step(const Tables& Tb, const Path& p, Trav&
     pop<BLOCK>(T, stk);
 }
 
-// STATS (diagnostic build only): counts, per phase, wave-level turns and the lanes that took part, into
-// work_counter[8..15] = {inner turns*64, inner lanes, leaf turns*64, leaf lanes, shade turns*64, shading
-// lanes, lanes that regenerated, descent-loop turns*64}.
-template <bool LDS16, int BLOCK, bool STATS>
+// MODE selects a diagnostic build of the same kernel:
+//   kModeStats   counts, per phase, wave-level turns and the lanes that took part, into the eight 64-bit words at
+//                work_counter + 8 = {inner turns*64, inner lanes, leaf turns*64, leaf lanes, shade turns*64, shading
+//                lanes, lanes that regenerated, descent-loop turns*64}; its inner-node loop is the compiled one
+//   kModeDump    the production code (assembly loops included) that also stores every finished path's colour to
+//                dump[(pixel * spp + sample - sample_begin) * 3]: what the parity tests compare path by path
+//   kModeTiming  the production code with a cycle stamp around every phase; one lane per wave adds, to the same
+//                eight words, {shade, descent-loop header, inner loop, leaf turn, whole kernel} cycles, waves, 0, 0
+constexpr int kModeProduction = 0, kModeStats = 1, kModeDump = 2, kModeTiming = 3;
+
+__device__ __forceinline__ uint64_t cycle_stamp() { return __builtin_amdgcn_s_memtime(); }
+// issue priority of this wave among the waves of its SIMD (s_setprio takes an immediate)
+__device__ __forceinline__ void set_wave_priority(uint32_t p) {
+    switch (p & 3u) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+
+template <bool LDS16, int BLOCK, int MODE>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void render_kernel_ws(SceneDev S, CamDev C, RenderParams P,
                                                           const Node16* __restrict__ nodes16, uint32_t stack_depth,
                                                           float* __restrict__ sum_rgb, float* __restrict__ partials,
-                                                          uint32_t* __restrict__ work_counter) {
+                                                          uint32_t* __restrict__ work_counter, float* __restrict__ dump) {
+    constexpr bool STATS = MODE == kModeStats, TIMING = MODE == kModeTiming, DUMP = MODE == kModeDump;
     uint32_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t cyc[5] = {0, 0, 0, 0, 0};
+    const uint64_t t_begin = TIMING ? cycle_stamp() : 0;
     extern __shared__ uint4 lds_raw[];
     // LDS layout (16-byte units): [q0: n_nodes][q1: n_nodes][spheres: 2*n_spheres][mat: n_prims]
     //                             [kind: n_prims/4][prim_id: n_prims/4][stack: stack_depth*BLOCK/4][hand-out state]
@@ -1073,8 +1101,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     uint4* lds_id = lds_kind + (LDS16 ? quads : 0);
     int32_t* stk0 = reinterpret_cast<int32_t*>(lds_id + (LDS16 ? quads : 0));
     int32_t* stk = stk0 + threadIdx.x;
-    volatile uint32_t* wave_state = reinterpret_cast<uint32_t*>(stk0 + stack_depth * BLOCK) + 4 * (threadIdx.x >> 6);
-    if ((threadIdx.x & 63) == 0) { wave_state[0] = 0; wave_state[1] = 64; }
+    lds_u32* wave_state = (lds_u32*)(reinterpret_cast<uint32_t*>(stk0 + stack_depth * BLOCK) + 4 * (threadIdx.x >> 6));
+    wave_state[0] = 0; wave_state[1] = 64; wave_state[2] = 0; wave_state[3] = 0;
     stk[0] = kLeafSentinel;
     if (LDS16) {
         const uint4* src = reinterpret_cast<const uint4*>(nodes16);
@@ -1112,12 +1140,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     const int trav_threshold = int(P.trav_threshold), inner_threshold = int(P.inner_threshold);
     const int leave_threshold = int(P.leave_threshold);
     const uint32_t q0_addr = lds_address(lds_q0), q1_addr = lds_address(lds_q1), stk_addr = lds_address(stk);
+    const uint32_t prio_inner = (P.flags >> 16) & 3u, prio_leaf = (P.flags >> 18) & 3u, prio_shade = (P.flags >> 20) & 3u;
+    const bool prio_used = (P.flags >> 16) & 63u;
 
     for (;;) {
+        if (prio_used) set_wave_priority(prio_shade);
         // ---- shade phase: every lane that is not descending.  One Philox block per lane and turn:
         // a path that scatters on draws (pixel, sample, bounce, 0), a path that ends makes room for
         // the pixel's next sample, whose camera ray draws (pixel, sample, 0, 0).
         if (STATS) st[4]++;
+        const uint64_t t_shade = TIMING ? cycle_stamp() : 0;
         if (T.node == kLeafSentinel && !done) {
             if (STATS) { st[5]++; if (!alive) st[6]++; }
             Surf sf;
@@ -1127,6 +1159,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                 if (!hit_part(S, Tb, P, p, T.best, sf, Lr, Lg, Lb)) {
                     ar += Lr; ag += Lg; ab += Lb;
                     alive = false;
+                    if (DUMP) {
+                        float* o = dump + 3 * (size_t(p.pixel) * (P.sample_end - P.sample_begin) + (p.sample - P.sample_begin));
+                        o[0] = Lr; o[1] = Lg; o[2] = Lb;
+                    }
                 }
             }
             if (!alive) {
@@ -1147,6 +1183,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                 if (have_pixel && next_sample < item_end) {
                     if (P.depth == 0) {
                         ar += 1.0f; ag += 1.0f; ab += 1.0f;
+                        if (DUMP) {
+                            float* o = dump + 3 * (size_t(p.pixel) * (P.sample_end - P.sample_begin) + (next_sample - P.sample_begin));
+                            o[0] = 1.0f; o[1] = 1.0f; o[2] = 1.0f;
+                        }
                     } else {
                         p.sample = next_sample;
                         fresh = true;
@@ -1165,10 +1205,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                 if (alive) trav_begin<!LDS16>(S, Tb, p, T);
             }
         }
+        if (TIMING) cyc[0] += cycle_stamp() - t_shade;
         if (__all(done)) break;
 
         // ---- descent phase
         for (;;) {
+            const uint64_t t_head = TIMING ? cycle_stamp() : 0;
             const bool descending = T.node != kLeafSentinel;
             const int n_desc = int(__popcll(__ballot(descending)));
             const bool someone_waits = __any(!descending && !done);
@@ -1178,6 +1220,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
             // left them (for a leaf or for good) since this run of steps began; a run never ends while lanes are on
             // inner nodes and none waits at a leaf
             const int run_threshold = max(inner_threshold, int(__popcll(__ballot(T.node >= 0))) - leave_threshold);
+            const uint64_t t_inner = TIMING ? cycle_stamp() : 0;
+            if (TIMING) cyc[1] += t_inner - t_head;
+            if (prio_used) set_wave_priority(prio_inner);
             if (LDS16 && !STATS) {
                 inner_loop_lds16<BLOCK>(T, q0_addr, q1_addr, stk_addr, run_threshold);
             } else if (!STATS) {
@@ -1190,14 +1235,25 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                     if (T.node >= 0) inner_step<LDS16, BLOCK>(S, lds_q0, lds_q1, T, stk);
                 }
             }
+            const uint64_t t_leaf = TIMING ? cycle_stamp() : 0;
+            if (TIMING) cyc[2] += t_leaf - t_inner;
+            if (prio_used) set_wave_priority(prio_leaf);
             if (STATS && __any(T.node < 0 && T.node != kLeafSentinel)) { st[2]++; if (T.node < 0 && T.node != kLeafSentinel) st[3]++; }
             if (T.node < 0 && T.node != kLeafSentinel) leaf_step<LDS16, BLOCK>(Tb, p, T, stk);
+            if (TIMING) cyc[3] += cycle_stamp() - t_leaf;
         }
     }
     if (STATS) {
         unsigned long long* out = reinterpret_cast<unsigned long long*>(work_counter + 8);
 #pragma unroll
         for (int i = 0; i < 8; ++i) atomicAdd(out + i, (unsigned long long)st[i]);
+    }
+    if (TIMING && (threadIdx.x & 63) == 0) {
+        cyc[4] = cycle_stamp() - t_begin;
+        unsigned long long* out = reinterpret_cast<unsigned long long*>(work_counter + 8);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) atomicAdd(out + i, (unsigned long long)cyc[i]);
+        atomicAdd(out + 5, 1ull);
     }
 }
 
@@ -1327,6 +1383,10 @@ struct rt_scene {
     uint32_t stack_depth = 0;
     int n_cu = 0;
     double bound_abs = 0.0;  // largest |coordinate| of any box corner
+    hipEvent_t ev_done = nullptr;  // recorded after every render of this handle: the next render waits for it, on any stream
+    // workgroups per CU of each render kernel variant for this scene's LDS footprint, 0 = not asked yet
+    // ([0] lock-step kernel, [1 + mode] wave-scheduled kernel with the tree in HBM, [5 + mode] with the scene in LDS)
+    int per_cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -1401,6 +1461,61 @@ float descent_eps(const rt_scene* sc, double origin_abs) {
 // LDS of the 256-thread kernels: the traversal stack plus four words of pixel hand-out state per wave
 size_t stack_bytes(const rt_scene* sc) { return size_t(std::max<uint32_t>(sc->stack_depth, 1u)) * kBlock * sizeof(int32_t) + 64; }  // 16 bytes of hand-out state per wave
 
+// LDS of one workgroup of the LDS-resident kernel: scene tables, the stack columns of kBlockLds lanes, hand-out state
+size_t lds16_launch_bytes(size_t scene_bytes, uint32_t stack_depth) {
+    return scene_bytes + size_t(std::max<uint32_t>(stack_depth, 1u)) * kBlockLds * sizeof(int32_t) + 16 * (kBlockLds / 64);
+}
+constexpr size_t kLdsPerCu = 160 * 1024;
+
+// Restores the calling thread's current HIP device when an entry point returns.
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+typedef void (*ws_kernel_t)(SceneDev, CamDev, RenderParams, const Node16*, uint32_t, float*, float*, uint32_t*, float*);
+ws_kernel_t ws_kernel(bool lds16, int mode) {
+    if (lds16) {
+        switch (mode) {
+        case kModeStats: return render_kernel_ws<true, kBlockLds, kModeStats>;
+        case kModeDump: return render_kernel_ws<true, kBlockLds, kModeDump>;
+        case kModeTiming: return render_kernel_ws<true, kBlockLds, kModeTiming>;
+        default: return render_kernel_ws<true, kBlockLds, kModeProduction>;
+        }
+    }
+    switch (mode) {
+    case kModeStats: return render_kernel_ws<false, kBlock, kModeStats>;
+    case kModeDump: return render_kernel_ws<false, kBlock, kModeDump>;
+    case kModeTiming: return render_kernel_ws<false, kBlock, kModeTiming>;
+    default: return render_kernel_ws<false, kBlock, kModeProduction>;
+    }
+}
+
+// Workgroups per CU of one kernel variant for this scene (asked once per scene and variant, then remembered;
+// the production variant is asked when the scene is created, so a render call makes no query).
+int resident_blocks(rt_scene* sc, bool lockstep, bool lds16, int mode, int* out) {
+    int& slot = sc->per_cu[lockstep ? 0 : 1 + (lds16 ? 4 : 0) + mode];
+    if (slot == 0) {
+        int per_cu = 0;
+        if (lockstep) {
+            RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel, kBlock, stack_bytes(sc)));
+        } else if (lds16) {
+            const size_t lds = lds16_launch_bytes(sc->lds16_scene_bytes, sc->stack_depth);
+            const ws_kernel_t k = ws_kernel(true, mode);
+            RT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsPerCu / 2)));
+            RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, kBlockLds, lds));
+        } else {
+            RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ws_kernel(false, mode), kBlock, stack_bytes(sc)));
+        }
+        slot = per_cu < 1 ? 1 : per_cu;
+    }
+    *out = slot;
+    return RT_OK;
+}
+
 int check_render_args(const rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, const char* who) {
     if (!scene || !cam || !opts) return fail(RT_ERR_INVALID_ARGUMENT, "%s: null argument", who);
     if (cam->horiz_res == 0 || cam->vert_res == 0) return fail(RT_ERR_INVALID_ARGUMENT, "%s: zero resolution", who);
@@ -1442,6 +1557,8 @@ RenderParams make_params(const rt_camera& cam, const rt_render_opts& o) {
     if (const char* e = std::getenv("RT_TRAV_THRESHOLD")) P.trav_threshold = uint32_t(std::atoi(e));    // tuning aid
     if (const char* e = std::getenv("RT_LEAVE_THRESHOLD")) P.leave_threshold = uint32_t(std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("RT_INNER_THRESHOLD")) P.inner_threshold = uint32_t(std::max(1, std::atoi(e)));
+    // tuning aid: issue priorities of the three phases, two bits each (inner loop | leaf turn << 2 | shade << 4)
+    if (const char* e = std::getenv("RT_PHASE_PRIORITY")) P.flags |= (uint32_t(std::atoi(e)) & 63u) << 16;
     return P;
 }
 
@@ -1463,7 +1580,9 @@ int rt_device_count(void) {
 
 void rt_scene_destroy(rt_scene* scene) {
     if (!scene) return;
+    DeviceGuard guard;
     (void)hipSetDevice(scene->device);
+    if (scene->ev_done) { (void)hipEventSynchronize(scene->ev_done); (void)hipEventDestroy(scene->ev_done); }
     if (scene->d_partials) (void)hipFree(scene->d_partials);
     for (void* p : scene->allocations) (void)hipFree(p);
     delete scene;
@@ -1513,6 +1632,7 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
     if (n_dev <= 0) return fail(RT_ERR_DEVICE, "rt_scene_create: no HIP device is visible");
     if (device < 0 || device >= n_dev) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: device %d of %d", device, n_dev);
 
+    DeviceGuard guard;
     rt_scene* sc = new rt_scene;
     sc->device = device;
     sc->hittables.assign(hittables, hittables + n_hittables);
@@ -1562,6 +1682,8 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
         tree_ids.erase(tree_ids.begin() + long(big));
     }
     std::sort(wide_ids.begin(), wide_ids.end());
+    // the assembly descent forms a node's byte offset (index * 32) in 32 bits
+    if (tree_ids.size() > (size_t(1) << 26)) return bail(fail(RT_ERR_LIMIT, "rt_scene_create: more than 2^26 spheres in the tree"));
 
     // BVH over the other spheres
     std::vector<double> sph4(4 * tree_ids.size());
@@ -1578,8 +1700,12 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
         build_bvh(sph4.data(), tree_ids.size(), lg + 7, &bvh);
     }
     sc->stack_depth = bvh.depth + 2;  // one pending entry per level, plus slot 0 (the sentinel below every stack)
+    // bound = largest |coordinate| of any surface point: path origins lie on surfaces (the wide spheres' too), and the
+    // origin widening of the f32 descent is sized from it
     double bound = 0.0;
     for (int a = 0; a < 3; ++a) bound = std::max(bound, std::max(std::fabs(bvh.scene_lo[a]), std::fabs(bvh.scene_hi[a])));
+    for (uint32_t id : wide_ids)
+        for (int a = 0; a < 3; ++a) bound = std::max(bound, std::fabs(hittables[id].centre[a]) + std::fabs(hittables[id].radius));
 
     // SoA primitive tables: spheres in leaf order, then discs in scene order
     const size_t n_s = sphere_ids.size(), n_d = disc_ids.size();
@@ -1647,8 +1773,7 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
     {
         const size_t n_prims = n_s + n_d;
         const size_t scene_bytes = 32 * bvh.nodes.size() + 32 * n_s + 16 * n_prims + 2 * 16 * ((n_prims + 3) / 4);
-        const size_t with_stack = scene_bytes + size_t(sc->stack_depth) * 512 * sizeof(int32_t);
-        if (n_s > 0 && with_stack <= 80 * 1024) {
+        if (n_s > 0 && lds16_launch_bytes(scene_bytes, sc->stack_depth) <= kLdsPerCu / 2) {
             std::vector<Node16> n16(bvh.nodes.size());
             for (size_t i = 0; i < bvh.nodes.size(); ++i) {
                 const Node& nd = bvh.nodes[i];
@@ -1726,6 +1851,12 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
     }
     if (stack_bytes(sc) > 64 * 1024)
         return bail(fail(RT_ERR_LIMIT, "rt_scene_create: BVH depth %u needs a %zu-byte LDS stack", bvh.depth, stack_bytes(sc)));
+    if (hipEventCreateWithFlags(&sc->ev_done, hipEventDisableTiming) != hipSuccess)
+        return bail(fail(RT_ERR_DEVICE, "rt_scene_create: hipEventCreate failed"));
+    {   // the production kernel's residency, asked here so that no render call has to
+        int per_cu = 0;
+        if ((rc = resident_blocks(sc, false, sc->d_nodes16 != nullptr, kModeProduction, &per_cu)) != RT_OK) return bail(rc);
+    }
 
     sc->info.n_hittables = n_hittables;
     sc->info.n_spheres = n_s;
@@ -1748,60 +1879,116 @@ int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out) {
     return RT_OK;
 }
 
-int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, float* d_sum_rgb, void* stream) {
-    int rc = check_render_args(scene, cam, opts, "rt_render_device");
-    if (rc != RT_OK) return rc;
-    if (!d_sum_rgb) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_device: null output buffer");
-    RT_HIP(hipSetDevice(scene->device));
-    hipStream_t st = static_cast<hipStream_t>(stream);
+namespace {
+
+// Grows the scene's partial-sum buffer to `need` bytes.  Waits for the handle's last render first: it may still be
+// writing the old buffer.
+int reserve_partials(rt_scene* scene, size_t need) {
+    if (need <= scene->partials_bytes) return RT_OK;
+    RT_HIP(hipEventSynchronize(scene->ev_done));
+    if (scene->d_partials) { (void)hipFree(scene->d_partials); scene->d_partials = nullptr; scene->partials_bytes = 0; }
+    RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_partials), need));
+    scene->partials_bytes = need;
+    return RT_OK;
+}
+
+size_t partials_needed(const RenderParams& P) {
+    return P.n_chunks > 1 ? size_t(P.n_chunks) * P.n_pixels * 3 * sizeof(float) : 0;
+}
+
+// The body of rt_render_device.  work_counter / partials: the scene's own, or the caller's (the entry point that
+// allocates nothing brings its own).  d_dump: per-path colours of the kModeDump build, else null.
+int launch_render(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, float* d_sum_rgb, hipStream_t st,
+                  uint32_t* d_work_counter, float* d_partials, float* d_dump) {
     SceneDev S = scene->dev;
     S.eps = descent_eps(scene, camera_abs(*cam));
     const CamDev C = make_cam(*cam);
     const RenderParams P = make_params(*cam, *opts);
     const uint64_t n_work = uint64_t(P.tiles_x) * P.tiles_y * 64u * P.n_chunks;
-    if (P.n_chunks > 1) {
-        const size_t need = size_t(P.n_chunks) * P.n_pixels * 3 * sizeof(float);
-        if (need > scene->partials_bytes) {  // grown on demand, kept for later renders of this scene
-            RT_HIP(hipStreamSynchronize(st));
-            if (scene->d_partials) { (void)hipFree(scene->d_partials); scene->d_partials = nullptr; scene->partials_bytes = 0; }
-            RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_partials), need));
-            scene->partials_bytes = need;
-        }
-    }
-    RT_HIP(hipMemsetAsync(scene->d_work_counter, 0, 256, st));
+    // one render of a handle at a time on the device: they share the work counter and the partial sums
+    RT_HIP(hipStreamWaitEvent(st, scene->ev_done, 0));
+    RT_HIP(hipMemsetAsync(d_work_counter, 0, 256, st));
     auto grid_for = [&](int per_cu, int block) {
         uint64_t blocks = uint64_t(scene->n_cu) * uint64_t(per_cu < 1 ? 1 : per_cu);
         return dim3(uint32_t(std::min<uint64_t>(blocks, (n_work + block - 1) / block)));
     };
-    int per_cu = 0;
-    if (opts->flags & RT_RENDER_KERNEL_LOCKSTEP) {
-        const size_t lds = stack_bytes(scene);
-        RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel, kBlock, lds));
-        hipLaunchKernelGGL(render_kernel, grid_for(per_cu, kBlock), dim3(kBlock), lds, st, S, C, P,
-                           std::max<uint32_t>(scene->stack_depth, 1u), d_sum_rgb, scene->d_partials, scene->d_work_counter);
+    int mode = kModeProduction;
+    if (d_dump) mode = kModeDump;
+    else if (opts->flags & RT_RENDER_STATS) mode = kModeStats;
+    else if (opts->flags & RT_RENDER_TIMING) mode = kModeTiming;
+    const uint32_t depth_slots = std::max<uint32_t>(scene->stack_depth, 1u);
+    int per_cu = 0, rc;
+    if ((opts->flags & RT_RENDER_KERNEL_LOCKSTEP) && !d_dump) {
+        if ((rc = resident_blocks(scene, true, false, 0, &per_cu)) != RT_OK) return rc;
+        hipLaunchKernelGGL(render_kernel, grid_for(per_cu, kBlock), dim3(kBlock), stack_bytes(scene), st, S, C, P, depth_slots,
+                           d_sum_rgb, d_partials, d_work_counter);
     } else if (scene->d_nodes16 && !(opts->flags & RT_RENDER_KERNEL_NO_LDS_SCENE)) {
-        constexpr int B = kBlockLds;
-        const size_t lds = scene->lds16_scene_bytes + size_t(std::max<uint32_t>(scene->stack_depth, 1u)) * B * sizeof(int32_t) + 16 * (B / 64);
-        auto k = (opts->flags & RT_RENDER_STATS) ? render_kernel_ws<true, B, true> : render_kernel_ws<true, B, false>;
-        RT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, B, lds));
-        hipLaunchKernelGGL(k, grid_for(per_cu, B), dim3(B), lds, st, S, C, P, scene->d_nodes16,
-                           std::max<uint32_t>(scene->stack_depth, 1u), d_sum_rgb, scene->d_partials, scene->d_work_counter);
+        if ((rc = resident_blocks(scene, false, true, mode, &per_cu)) != RT_OK) return rc;
+        hipLaunchKernelGGL(ws_kernel(true, mode), grid_for(per_cu, kBlockLds), dim3(kBlockLds),
+                           lds16_launch_bytes(scene->lds16_scene_bytes, scene->stack_depth), st, S, C, P, scene->d_nodes16, depth_slots,
+                           d_sum_rgb, d_partials, d_work_counter, d_dump);
     } else {
-        const size_t lds = stack_bytes(scene);
-        auto k = (opts->flags & RT_RENDER_STATS) ? render_kernel_ws<false, kBlock, true> : render_kernel_ws<false, kBlock, false>;
-        RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, kBlock, lds));
-        hipLaunchKernelGGL(k, grid_for(per_cu, kBlock), dim3(kBlock), lds, st, S, C, P, static_cast<const Node16*>(nullptr),
-                           std::max<uint32_t>(scene->stack_depth, 1u), d_sum_rgb, scene->d_partials, scene->d_work_counter);
+        if ((rc = resident_blocks(scene, false, false, mode, &per_cu)) != RT_OK) return rc;
+        hipLaunchKernelGGL(ws_kernel(false, mode), grid_for(per_cu, kBlock), dim3(kBlock), stack_bytes(scene), st, S, C, P,
+                           static_cast<const Node16*>(nullptr), depth_slots, d_sum_rgb, d_partials, d_work_counter, d_dump);
     }
     RT_HIP(hipGetLastError());
     if (P.n_chunks > 1) {
         const size_t n = size_t(P.n_pixels) * 3;
-        hipLaunchKernelGGL(combine_kernel, dim3(uint32_t((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, scene->d_partials, P.n_chunks, n,
+        hipLaunchKernelGGL(combine_kernel, dim3(uint32_t((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, d_partials, P.n_chunks, n,
                            uint32_t(opts->flags & RT_RENDER_ACCUMULATE), d_sum_rgb);
         RT_HIP(hipGetLastError());
     }
+    RT_HIP(hipEventRecord(scene->ev_done, st));
     return RT_OK;
+}
+
+}  // namespace
+
+int rt_scene_reserve(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts) {
+    int rc = check_render_args(scene, cam, opts, "rt_scene_reserve");
+    if (rc != RT_OK) return rc;
+    DeviceGuard guard;
+    RT_HIP(hipSetDevice(scene->device));
+    return reserve_partials(scene, partials_needed(make_params(*cam, *opts)));
+}
+
+int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, float* d_sum_rgb, void* stream) {
+    int rc = check_render_args(scene, cam, opts, "rt_render_device");
+    if (rc != RT_OK) return rc;
+    if (!d_sum_rgb) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_device: null output buffer");
+    DeviceGuard guard;
+    RT_HIP(hipSetDevice(scene->device));
+    // grown on first use unless rt_scene_reserve has sized it (the one case in which this call waits and allocates)
+    if ((rc = reserve_partials(scene, partials_needed(make_params(*cam, *opts)))) != RT_OK) return rc;
+    return launch_render(scene, cam, opts, d_sum_rgb, static_cast<hipStream_t>(stream), scene->d_work_counter, scene->d_partials, nullptr);
+}
+
+int rt_debug_render_paths(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, float* rgb) {
+    int rc = check_render_args(scene, cam, opts, "rt_debug_render_paths");
+    if (rc != RT_OK) return rc;
+    if (!rgb) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_render_paths: null output buffer");
+    if (opts->flags & RT_RENDER_ACCUMULATE) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_render_paths: RT_RENDER_ACCUMULATE has no meaning here");
+    DeviceGuard guard;
+    RT_HIP(hipSetDevice(scene->device));
+    const size_t n_pixels = size_t(cam->horiz_res) * cam->vert_res;
+    const size_t n_paths = n_pixels * (opts->sample_end - opts->sample_begin);
+    if (n_paths > (size_t(1) << 28)) return fail(RT_ERR_LIMIT, "rt_debug_render_paths: more than 2^28 paths in one call");
+    if ((rc = reserve_partials(scene, partials_needed(make_params(*cam, *opts)))) != RT_OK) return rc;
+    float *d_sum = nullptr, *d_dump = nullptr;
+    RT_HIP(hipMalloc(reinterpret_cast<void**>(&d_sum), n_pixels * 3 * sizeof(float)));
+    if (hipMalloc(reinterpret_cast<void**>(&d_dump), n_paths * 3 * sizeof(float)) != hipSuccess) {
+        (void)hipFree(d_sum);
+        return fail(RT_ERR_DEVICE, "rt_debug_render_paths: hipMalloc failed");
+    }
+    if (hipMemset(d_dump, 0, n_paths * 3 * sizeof(float)) != hipSuccess) rc = fail(RT_ERR_DEVICE, "rt_debug_render_paths: hipMemset failed");
+    if (rc == RT_OK) rc = launch_render(scene, cam, opts, d_sum, nullptr, scene->d_work_counter, scene->d_partials, d_dump);
+    if (rc == RT_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(RT_ERR_DEVICE, "rt_debug_render_paths: kernel execution failed");
+    if (rc == RT_OK && hipMemcpy(rgb, d_dump, n_paths * 3 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(RT_ERR_DEVICE, "rt_debug_render_paths: download failed");
+    (void)hipFree(d_sum);
+    (void)hipFree(d_dump);
+    return rc;
 }
 
 int rt_render_chunk(const rt_camera* cam, const rt_render_opts* opts, uint32_t* samples_per_item) {
@@ -1813,6 +2000,7 @@ int rt_render_chunk(const rt_camera* cam, const rt_render_opts* opts, uint32_t* 
 
 int rt_debug_render_stats(rt_scene* scene, uint64_t out[8]) {
     if (!scene || !out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_render_stats: null argument");
+    DeviceGuard guard;
     RT_HIP(hipSetDevice(scene->device));
     RT_HIP(hipDeviceSynchronize());
     RT_HIP(hipMemcpy(out, scene->d_work_counter + 8, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
@@ -1821,18 +2009,12 @@ int rt_debug_render_stats(rt_scene* scene, uint64_t out[8]) {
 
 int rt_debug_render_launch(rt_scene* scene, uint32_t* block_threads, uint32_t* workgroups_per_cu, uint32_t* waves_per_simd) {
     if (!scene || !block_threads || !workgroups_per_cu || !waves_per_simd) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_render_launch: null argument");
+    DeviceGuard guard;
     RT_HIP(hipSetDevice(scene->device));
-    int per_cu = 0, block = 0;
-    if (scene->d_nodes16) {
-        block = kBlockLds;
-        const size_t lds = scene->lds16_scene_bytes + size_t(std::max<uint32_t>(scene->stack_depth, 1u)) * kBlockLds * sizeof(int32_t) + 16 * (kBlockLds / 64);
-        auto k = render_kernel_ws<true, kBlockLds, false>;
-        RT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, block, lds));
-    } else {
-        block = kBlock;
-        RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel_ws<false, kBlock, false>, block, stack_bytes(scene)));
-    }
+    const bool lds16 = scene->d_nodes16 != nullptr;
+    const int block = lds16 ? kBlockLds : kBlock;
+    int per_cu = 0;
+    if (int rc = resident_blocks(scene, false, lds16, kModeProduction, &per_cu)) return rc;
     *block_threads = uint32_t(block);
     *workgroups_per_cu = uint32_t(per_cu);
     *waves_per_simd = uint32_t(per_cu * (block / 64) / 4);
@@ -1843,6 +2025,7 @@ int rt_finalize_device(const rt_scene* scene, const float* d_sum_rgb, size_t n_p
                        void* stream) {
     if (!scene || !d_sum_rgb || !d_rgb8) return fail(RT_ERR_INVALID_ARGUMENT, "rt_finalize_device: null argument");
     if (spp_total == 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_finalize_device: spp_total is zero");
+    DeviceGuard guard;
     RT_HIP(hipSetDevice(scene->device));
     const size_t n = n_pixels * 3;
     if (n == 0) return RT_OK;
@@ -1855,6 +2038,7 @@ int rt_finalize_device(const rt_scene* scene, const float* d_sum_rgb, size_t n_p
 int rt_render(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, float* sum_rgb, uint8_t* rgb8) {
     int rc = check_render_args(scene, cam, opts, "rt_render");
     if (rc != RT_OK) return rc;
+    DeviceGuard guard;
     RT_HIP(hipSetDevice(scene->device));
     const size_t n_pixels = size_t(cam->horiz_res) * cam->vert_res;
     float* d_sum = nullptr;
@@ -1881,6 +2065,57 @@ int rt_render(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts,
     return rc;
 }
 
+namespace {
+
+// RCCL, bound at the first multi-device render: the single-device paths then carry no dependency on it.
+// Only the five calls below are used; types follow rccl.h (ncclComm_t is an opaque pointer, ncclFloat32 = 7, ncclSum = 0).
+struct Rccl {
+    void* so = nullptr;
+    int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+    int (*CommDestroy)(void* comm) = nullptr;
+    int (*Reduce)(const void* send, void* recv, size_t count, int dtype, int op, int root, void* comm, hipStream_t st) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::vector<int> devices;   // the device list of `comms` (one communicator set is kept: renders reuse it)
+    std::vector<void*> comms;
+    bool tried = false;
+
+    bool load() {
+        if (tried) return so != nullptr;
+        tried = true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            so = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (so) break;
+        }
+        if (!so) return false;
+        auto sym = [&](const char* n) { return dlsym(so, n); };
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(sym("ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+        Reduce = reinterpret_cast<decltype(Reduce)>(sym("ncclReduce"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+        if (!CommInitAll || !CommDestroy || !Reduce || !GroupStart || !GroupEnd || !GetErrorString) { dlclose(so); so = nullptr; }
+        return so != nullptr;
+    }
+    // communicators over exactly these devices, in this order (rank g = devs[g])
+    int communicators(const std::vector<int>& devs) {
+        if (devs == devices && !comms.empty()) return RT_OK;
+        for (void* c : comms) (void)CommDestroy(c);
+        comms.assign(devs.size(), nullptr);
+        devices.clear();
+        const int r = CommInitAll(comms.data(), int(devs.size()), devs.data());
+        if (r != 0) { comms.clear(); return fail(RT_ERR_DEVICE, "rt_render_multi: ncclCommInitAll failed: %s", GetErrorString(r)); }
+        devices = devs;
+        return RT_OK;
+    }
+};
+Rccl g_rccl;
+std::mutex g_rccl_mutex;
+
+}  // namespace
+
 int rt_render_multi(rt_scene* const* scenes, size_t n_scenes, const rt_camera* cam, const rt_render_opts* opts, float* sum_rgb,
                     uint8_t* rgb8) {
     if (!scenes || n_scenes == 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_multi: no scene handles");
@@ -1888,22 +2123,58 @@ int rt_render_multi(rt_scene* const* scenes, size_t n_scenes, const rt_camera* c
     for (size_t g = 0; g < n_scenes; ++g) {
         int rc = check_render_args(scenes[g], cam, opts, "rt_render_multi");
         if (rc != RT_OK) return rc;
+        for (size_t k = 0; k < g; ++k)
+            if (scenes[k] == scenes[g]) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_multi: handle %zu is handle %zu again", g, k);
     }
     if (opts->flags & RT_RENDER_ACCUMULATE) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_multi: RT_RENDER_ACCUMULATE is not supported here");
     const uint32_t spp = opts->sample_end - opts->sample_begin;
     if (spp < n_scenes) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_multi: %u samples for %zu devices", spp, n_scenes);
-    const size_t n_pixels = size_t(cam->horiz_res) * cam->vert_res, bytes = n_pixels * 3 * sizeof(float);
+    const size_t n_pixels = size_t(cam->horiz_res) * cam->vert_res, n_channels = n_pixels * 3, bytes = n_channels * sizeof(float);
+    DeviceGuard guard;
+    const int dev0 = scenes[0]->device;
+    std::vector<int> devs(n_scenes);
+    bool distinct = true;
+    for (size_t g = 0; g < n_scenes; ++g) {
+        devs[g] = scenes[g]->device;
+        for (size_t k = 0; k < g; ++k) distinct = distinct && devs[k] != devs[g];
+    }
+    // How the partial images meet on the first device.  "rccl": one ncclReduce(sum) to rank 0 over xGMI (needs one
+    // handle per DIFFERENT device; the library picks the order of the additions).  "peer": every device copies its
+    // image into a landing slot of its own on the first device, all copies in flight at once, and one kernel adds the
+    // slots in handle order.  Default: rccl where it applies and loads, else peer.
+    const char* how = std::getenv("RT_MULTI_REDUCE");
+    const bool force_rccl = how && std::strcmp(how, "rccl") == 0, force_peer = how && std::strcmp(how, "peer") == 0;
+    if (how && !force_rccl && !force_peer) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_multi: RT_MULTI_REDUCE is '%s' (rccl or peer)", how);
+    if (force_rccl && !distinct) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_multi: RT_MULTI_REDUCE=rccl needs every handle on a different device");
+    bool use_rccl = distinct && !force_peer && (n_scenes > 1 || force_rccl);
+    std::unique_lock<std::mutex> rccl_lock(g_rccl_mutex, std::defer_lock);
+    if (use_rccl) {
+        rccl_lock.lock();
+        if (!g_rccl.load()) {
+            if (force_rccl) return fail(RT_ERR_DEVICE, "rt_render_multi: librccl.so could not be loaded: %s", dlerror());
+            use_rccl = false;
+            rccl_lock.unlock();
+        }
+    }
+
     std::vector<float*> d_sum(n_scenes, nullptr);
     std::vector<hipStream_t> streams(n_scenes, nullptr);
-    float* d_tmp = nullptr;
+    std::vector<hipEvent_t> landed(n_scenes, nullptr);
+    float* d_land = nullptr;  // n_scenes - 1 landing slots on the first device (peer path)
     uint8_t* d_rgb = nullptr;
     int rc = RT_OK;
     auto chk = [&](hipError_t e, const char* what) {
         if (e != hipSuccess && rc == RT_OK) rc = fail(RT_ERR_DEVICE, "rt_render_multi: %s failed: %s", what, hipGetErrorString(e));
     };
-    // every device traces its share of the sample indices at the same time, each on a stream of its own
+    if (use_rccl) rc = g_rccl.communicators(devs);
+    if (rc == RT_OK && !use_rccl && n_scenes > 1) {
+        chk(hipSetDevice(dev0), "hipSetDevice");
+        chk(hipMalloc(reinterpret_cast<void**>(&d_land), bytes * (n_scenes - 1)), "hipMalloc");
+    }
+    // every device traces its share of the sample indices at the same time, each on a stream of its own; on the peer
+    // path its copy to the first device follows on the same stream
     for (size_t g = 0; g < n_scenes && rc == RT_OK; ++g) {
-        chk(hipSetDevice(scenes[g]->device), "hipSetDevice");
+        chk(hipSetDevice(devs[g]), "hipSetDevice");
         chk(hipStreamCreateWithFlags(&streams[g], hipStreamNonBlocking), "hipStreamCreate");
         chk(hipMalloc(reinterpret_cast<void**>(&d_sum[g]), bytes), "hipMalloc");
         if (rc != RT_OK) break;
@@ -1911,22 +2182,37 @@ int rt_render_multi(rt_scene* const* scenes, size_t n_scenes, const rt_camera* c
         o.sample_begin = opts->sample_begin + uint32_t(uint64_t(spp) * g / n_scenes);
         o.sample_end = opts->sample_begin + uint32_t(uint64_t(spp) * (g + 1) / n_scenes);
         rc = rt_render_device(scenes[g], cam, &o, d_sum[g], streams[g]);
+        if (rc != RT_OK || use_rccl || g == 0) continue;
+        if (devs[g] != dev0) {  // direct xGMI access where the pair allows it; the copy below works either way
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devs[g], dev0) == hipSuccess && can) {
+                const hipError_t e = hipDeviceEnablePeerAccess(dev0, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) chk(e, "hipDeviceEnablePeerAccess");
+                (void)hipGetLastError();
+            }
+        }
+        chk(hipMemcpyPeerAsync(d_land + (g - 1) * n_channels, dev0, d_sum[g], devs[g], bytes, streams[g]), "hipMemcpyPeerAsync");
+        chk(hipEventCreateWithFlags(&landed[g], hipEventDisableTiming), "hipEventCreate");
+        chk(hipEventRecord(landed[g], streams[g]), "hipEventRecord");
     }
-    // the one exchange: the partial images are added on the first device, in handle order (a fixed summation order)
-    const int dev0 = scenes[0]->device;
-    if (rc == RT_OK && n_scenes > 1) {
+    // the one exchange
+    if (rc == RT_OK && use_rccl) {
+        int r = g_rccl.GroupStart();
+        for (size_t g = 0; g < n_scenes && r == 0; ++g) {
+            chk(hipSetDevice(devs[g]), "hipSetDevice");
+            r = g_rccl.Reduce(d_sum[g], d_sum[g], n_channels, /*ncclFloat32*/ 7, /*ncclSum*/ 0, 0, g_rccl.comms[g], streams[g]);
+        }
+        const int r_end = g_rccl.GroupEnd();
+        if (r == 0) r = r_end;
+        if (r != 0 && rc == RT_OK) rc = fail(RT_ERR_DEVICE, "rt_render_multi: ncclReduce failed: %s", g_rccl.GetErrorString(r));
+    } else if (rc == RT_OK && n_scenes > 1) {
         chk(hipSetDevice(dev0), "hipSetDevice");
-        chk(hipMalloc(reinterpret_cast<void**>(&d_tmp), bytes), "hipMalloc");
-    }
-    for (size_t g = 1; g < n_scenes && rc == RT_OK; ++g) {
-        chk(hipSetDevice(scenes[g]->device), "hipSetDevice");
-        chk(hipStreamSynchronize(streams[g]), "render on a device");
-        chk(hipSetDevice(dev0), "hipSetDevice");
-        chk(hipMemcpyPeerAsync(d_tmp, dev0, d_sum[g], scenes[g]->device, bytes, streams[0]), "hipMemcpyPeerAsync");
-        if (rc != RT_OK) break;
-        const size_t n = n_pixels * 3;
-        hipLaunchKernelGGL(combine_kernel, dim3(uint32_t((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, streams[0], d_tmp, 1u, n, 1u, d_sum[0]);
-        chk(hipGetLastError(), "combine_kernel");
+        for (size_t g = 1; g < n_scenes; ++g) chk(hipStreamWaitEvent(streams[0], landed[g], 0), "hipStreamWaitEvent");
+        if (rc == RT_OK) {
+            hipLaunchKernelGGL(combine_kernel, dim3(uint32_t((n_channels + kBlock - 1) / kBlock)), dim3(kBlock), 0, streams[0], d_land,
+                               uint32_t(n_scenes - 1), n_channels, 1u, d_sum[0]);
+            chk(hipGetLastError(), "combine_kernel");
+        }
     }
     if (rc == RT_OK) chk(hipSetDevice(dev0), "hipSetDevice");
     if (rc == RT_OK && rgb8) {
@@ -1937,12 +2223,13 @@ int rt_render_multi(rt_scene* const* scenes, size_t n_scenes, const rt_camera* c
     if (rc == RT_OK && sum_rgb) chk(hipMemcpy(sum_rgb, d_sum[0], bytes, hipMemcpyDeviceToHost), "download");
     if (rc == RT_OK && rgb8) chk(hipMemcpy(rgb8, d_rgb, n_pixels * 3, hipMemcpyDeviceToHost), "download");
     for (size_t g = 0; g < n_scenes; ++g) {
-        if (hipSetDevice(scenes[g]->device) != hipSuccess) continue;
+        if (hipSetDevice(devs[g]) != hipSuccess) continue;
         if (streams[g]) { (void)hipStreamSynchronize(streams[g]); (void)hipStreamDestroy(streams[g]); }
+        if (landed[g]) (void)hipEventDestroy(landed[g]);
         if (d_sum[g]) (void)hipFree(d_sum[g]);
     }
     if (hipSetDevice(dev0) == hipSuccess) {
-        if (d_tmp) (void)hipFree(d_tmp);
+        if (d_land) (void)hipFree(d_land);
         if (d_rgb) (void)hipFree(d_rgb);
     }
     return rc;
@@ -1952,6 +2239,7 @@ int rt_trace_primary(rt_scene* scene, const float* orig, const float* dir, size_
     if (!scene || !orig || !dir || !id || !t || !normal) return fail(RT_ERR_INVALID_ARGUMENT, "rt_trace_primary: null argument");
     if (n == 0) return RT_OK;
     if (n > 0x7fffffffull - kBlock) return fail(RT_ERR_LIMIT, "rt_trace_primary: more than 2^31 rays in one call");
+    DeviceGuard guard;
     RT_HIP(hipSetDevice(scene->device));
     double origin_abs = 0.0;
     for (size_t i = 0; i < 3 * n; ++i) {
@@ -2005,6 +2293,7 @@ int rt_generate_primary(rt_scene* scene, const rt_camera* cam, uint64_t seed, ui
     const uint64_t ns = sample_end - sample_begin, n = uint64_t(pixel_end - pixel_begin) * ns;
     if (n == 0) return RT_OK;
     if (n > 0x7fffffffull - kBlock) return fail(RT_ERR_LIMIT, "rt_generate_primary: more than 2^31 rays in one call");
+    DeviceGuard guard;
     RT_HIP(hipSetDevice(scene->device));
     float *d_o = nullptr, *d_d = nullptr;
     RT_HIP(hipMalloc(reinterpret_cast<void**>(&d_o), 3 * n * sizeof(float)));
@@ -2042,6 +2331,7 @@ int rt_trace_path_segments(rt_scene* scene, const rt_camera* cam, const rt_rende
     const uint64_t n_pixels = uint64_t(cam->horiz_res) * cam->vert_res;
     for (size_t k = 0; k < n; ++k)
         if (pixel[k] >= n_pixels) return fail(RT_ERR_INVALID_ARGUMENT, "rt_trace_paths: pixel %u of %llu", pixel[k], (unsigned long long)n_pixels);
+    DeviceGuard guard;
     RT_HIP(hipSetDevice(scene->device));
     uint32_t *d_p = nullptr, *d_s = nullptr, *d_nseg = nullptr;
     float* d_rgb = nullptr;

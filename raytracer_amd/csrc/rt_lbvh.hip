@@ -98,7 +98,7 @@ __global__ void refit_kernel(const double4* __restrict__ sph, const uint32_t* __
     const int k = int(blockIdx.x * blockDim.x + threadIdx.x);
     if (k >= n) return;
     const double4 s = sph[order[k]];
-    const double r = s.w;  // as given, like the host builder and src/boundingvolume.rs:246-248
+    const double r = fabs(s.w);  // like the host builder: src/boundingvolume.rs:246-248 with |r|
     float lo[3] = {__double2float_rd(s.x - r), __double2float_rd(s.y - r), __double2float_rd(s.z - r)};
     float hi[3] = {__double2float_ru(s.x + r), __double2float_ru(s.y + r), __double2float_ru(s.z + r)};
     int32_t levels = 0;
@@ -143,7 +143,7 @@ int build_lbvh_device(const double* spheres, size_t n, BuiltBvh* out) {
         const double* s = spheres + 4 * i;
         for (int a = 0; a < 3; ++a) {
             clo[a] = std::min(clo[a], s[a]); chi[a] = std::max(chi[a], s[a]);
-            slo[a] = std::min(slo[a], s[a] - s[3]); shi[a] = std::max(shi[a], s[a] + s[3]);
+            slo[a] = std::min(slo[a], s[a] - std::fabs(s[3])); shi[a] = std::max(shi[a], s[a] + std::fabs(s[3]));
         }
     }
     for (int a = 0; a < 3; ++a) { out->scene_lo[a] = slo[a]; out->scene_hi[a] = shi[a]; }

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--stats", action="store_true")
+    ap.add_argument("--timing", action="store_true", help="production kernel with a cycle stamp around each phase")
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -61,7 +62,7 @@ def main():
     H, W = cam.vert_res, cam.horiz_res
     d_sum = torch.zeros(H, W, 3, dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
-    flags = a.flags | (_abi.RT_RENDER_STATS if a.stats else 0)
+    flags = a.flags | (_abi.RT_RENDER_STATS if a.stats else 0) | (_abi.RT_RENDER_TIMING if a.timing else 0)
     scene.render_device(cam, d_sum.data_ptr(), 0, spp, depth, 0, stream=stream, flags=flags, samples_per_item=a.chunk)
     torch.cuda.synchronize()
     ms = []
@@ -88,6 +89,13 @@ def main():
                         "leaf_lane_util": round(o[3] / max(o[2], 1), 3), "shade_lane_util": round(o[5] / max(o[4], 1), 3)}
         out["algorithmic_bytes_per_segment"] = roofline.bytes_per_segment(len(h))
         out["executed_node_bytes_per_path"] = round(o[1] / paths * 32 + o[3] / paths * 32, 1)  # 32-byte nodes (f16 in LDS or 16-bit grid in HBM), 32-byte spheres
+    if a.timing:
+        st = np.zeros(8, dtype=np.uint64)
+        _abi.check(_abi.lib.rt_debug_render_stats(scene.handle, st.ctypes.data))
+        o = st.astype(float)
+        total = max(o[4], 1.0)
+        out["timing"] = {"shade": round(o[0] / total, 4), "descent_header": round(o[1] / total, 4), "inner_loop": round(o[2] / total, 4),
+                         "leaf_turn": round(o[3] / total, 4), "waves": int(o[5]), "wave_cycles_per_path": round(total / (W * H * spp), 1)}
     print(json.dumps(out), flush=True)
 
 

@@ -62,6 +62,7 @@ def lib():
         L.orc_scene_build_tree.argtypes = [vp]
         L.orc_scene_tree_depth.argtypes = [vp]
         L.orc_scene_set_tie_rule.argtypes = [vp, i]
+        L.orc_scene_set_dir_noise.argtypes = [vp, d]
         L.orc_camera_build.argtypes = [C.POINTER(d), C.POINTER(d), d, d, u32, u32, C.POINTER(Camera)]
         L.orc_gen_scene.restype = sz
         L.orc_gen_scene.argtypes = [u64, vp, sz]
@@ -139,6 +140,10 @@ class Scene:
 
     def set_tie_lowest_index(self, on):
         lib().orc_scene_set_tie_rule(self.handle, 1 if on else 0)
+
+    def set_dir_noise(self, amplitude):
+        """Test aid: move every ray direction by up to `amplitude` per component before tracing it (0 = off)."""
+        lib().orc_scene_set_dir_noise(self.handle, float(amplitude))
 
     def trace(self, orig, dirs, traverse=TRAVERSE_GATED_BRUTE):
         o, d = f64(orig).reshape(-1, 3), f64(dirs).reshape(-1, 3)

@@ -12,6 +12,10 @@ from conftest import golden
 pytestmark = pytest.mark.gpu
 
 T_REL = 1e-5  # tolerance the parity target states for t and normals
+# Largest difference, per component, between a ray direction the device forms (f32 arithmetic, one-instruction
+# rcp / sqrt / sin / cos) and the oracle's f64 value of the same formula; test_generate_primary_matches_oracle
+# holds the camera rays to it.
+DIR_ERR = 5e-6
 
 
 @pytest.fixture(scope="module")
@@ -83,7 +87,7 @@ def test_generate_primary_matches_oracle(scene1, ob, rt):
     cam = rt.default_camera(96, 64)
     o, d = scene1.generate_primary(cam, seed=5, pixel_begin=100, pixel_end=1100, sample_begin=2, sample_end=5)
     wo, wd = ob.generate_primary(_ocam(ob, cam), 5, 100, 1100, 2, 5)
-    assert np.abs(o - wo).max() < 5e-6 and np.abs(d - wd).max() < 5e-6  # f32 camera arithmetic vs f64
+    assert np.abs(o - wo).max() < DIR_ERR and np.abs(d - wd).max() < DIR_ERR  # f32 camera arithmetic vs f64
     assert np.allclose(np.linalg.norm(d.astype(np.float64), axis=1), 1, atol=3e-7)  # Ray::new normalises
     # lens samples stay in the positive quarter disc (src/camera.rs:81-89)
     rel = (o.astype(np.float64) - cam.field("lookfrom")) / 0.1
@@ -116,8 +120,27 @@ def _path_parity(scene, oscene, cam, ocam, ob, n_pixels, spp, depth, seed, trave
     both = (gi == wi) & (wi >= 0) & same_ids[:, None]
     first = both[:, 0]
     assert np.all(np.abs(gt[first, 0] - wt[first, 0]) <= T_REL * np.abs(wt[first, 0]))  # f32 vs f64 camera arithmetic only
-    # later vertices drift (a grazing hit magnifies a 1e-7 change of direction), but only a few of them
-    assert np.mean(np.abs(gt[both] - wt[both]) <= 1e-4 * np.maximum(np.abs(wt[both]), 0.1)) > 0.97
+    # Later vertices drift: a bounce off a sphere of radius r magnifies a direction error by about (distance / r),
+    # so no fixed tolerance holds along a whole path.  How much drift an error of DIR_ERR per direction causes on
+    # THESE paths is measured on the oracle itself (the same paths traced again with every direction moved by up to
+    # DIR_ERR); the device, whose direction error is below DIR_ERR, must agree with the oracle at least as often.
+    def within(t, ids, n):
+        ok = (ids == wi) & (wi >= 0) & (np.all(ids == wi, axis=1) & (n == wn))[:, None]
+        return ok, np.abs(t - wt) <= 1e-4 * np.maximum(np.abs(wt), 0.1)
+    oscene.set_dir_noise(DIR_ERR)
+    try:
+        ni, nt, nn = oscene.path_segments(ocam, pixel, sample, depth=depth, seed=seed, traverse=traverse, max_segments=m)
+    finally:
+        oscene.set_dir_noise(0.0)
+    ok_n, in_n = within(nt, ni, nn)
+    ok_g, in_g = within(gt, gi, gn)
+    expected = (ok_n & in_n).sum() / max((wi >= 0).sum(), 1)  # vertices that survive the stated direction error
+    observed = (ok_g & in_g).sum() / max((wi >= 0).sum(), 1)
+    assert observed >= expected - 0.005, (observed, expected)
+    # the same yardstick for whole ID sequences: the share of glass-free paths whose sequence survives the stated
+    # direction error; the callers hold the device to min(0.999, that share)
+    noise_same = np.all(ni == wi, axis=1) & (nn == wn)
+    _path_parity.id_floor = min(0.999, float(noise_same[calm].mean()) - 0.0005) if calm.any() else 0.999
     return got, want, close, same_ids, calm
 
 
@@ -343,6 +366,151 @@ def test_nested_dielectric_shells_deep_bounces(rt, ob, earth_rgb8):
     assert abs(got.mean() - want.mean()) < 1e-2 * want.mean()
 
 
+def _render_paths_against_oracle(scene, oscene, cam, ocam, ob, spp, depth, seed, traverse, hittables):
+    """Per-path colours from the RENDER kernel itself (production code built with one extra store per path)
+    against the oracle on the same counters.  Returns (got, want, close, calm) over all W*H*spp paths."""
+    n = cam.horiz_res * cam.vert_res
+    got = scene.render_paths(cam, spp, depth=depth, seed=seed).reshape(n * spp, 3).astype(np.float64)
+    pixel = np.repeat(np.arange(n, dtype=np.uint32), spp)
+    sample = np.tile(np.arange(spp, dtype=np.uint32), n)
+    want = oscene.trace_paths(ocam, pixel, sample, depth=depth, seed=seed, traverse=traverse, sampler=ob.SAMPLER_DIRECT)
+    wi, _, _ = oscene.path_segments(ocam, pixel, sample, depth=depth, seed=seed, traverse=traverse, max_segments=min(depth, 12))
+    mat = np.asarray(hittables["material"])
+    calm = ~np.any((wi >= 0) & (mat[np.maximum(wi, 0)] == 2), axis=1)
+    close = np.all(np.abs(got - want) <= 2e-4 * np.maximum(1.0, np.abs(want)), axis=1)
+    # the dump is the image: summed in the render's chunk order it gives the render's sums bit for bit
+    img, _ = scene.render(cam, spp, depth=depth, seed=seed)
+    chunk = scene.render_chunk(cam, spp)
+    cols = got.reshape(n, spp, 3).astype(np.float32)
+    total = np.zeros((n, 3), dtype=np.float32)
+    for c0 in range(0, spp, chunk):
+        part = np.zeros((n, 3), dtype=np.float32)
+        for k in range(c0, min(c0 + chunk, spp)):
+            part += cols[:, k, :]
+        total += part
+    assert np.array_equal(total.reshape(cam.vert_res, cam.horiz_res, 3), img)
+    # and it is what the per-path entry point returns (same arithmetic, different kernel)
+    assert np.array_equal(got.astype(np.float32), scene.trace_paths(cam, pixel, sample, depth=depth, seed=seed))
+    return got, want, close, calm
+
+
+def test_render_kernel_paths_lds_scene_against_oracle(scene1, oscene1, ob, rt):
+    # the kernel of the bench workload: scene in LDS, f16 boxes, assembly inner loop
+    assert scene1.info["lds_resident"] == 1
+    cam = rt.default_camera(96, 54)
+    got, want, close, calm = _render_paths_against_oracle(scene1, oscene1, cam, _ocam(ob, cam), ob, 3, 50, 5,
+                                                          ob.TRAVERSE_GATED_BRUTE, scene1.hittables)
+    assert calm.mean() > 0.9 and close[calm].mean() > 0.998
+    assert abs(got.mean() - want.mean()) < 5e-3 * want.mean()
+
+
+def test_render_kernel_paths_hbm_tree_against_oracle(rt, ob):
+    # 2305 spheres: too large for LDS, so the render kernel walks the quantised tree in HBM (inner_loop_hbm)
+    h = rt.gen_scene_grid(2, 48)
+    scene, oscene = rt.Scene(h), ob.Scene(h)
+    assert scene.info["lds_resident"] == 0
+    cam = rt.Camera.build([0, 0, 0], [20, 6, 8], 1.0, 0.05, 96, 60)
+    ocam = _ocam(ob, cam)
+    got, want, close, calm = _render_paths_against_oracle(scene, oscene, cam, ocam, ob, 2, 50, 3, ob.TRAVERSE_GATED_BRUTE, h)
+    assert calm.mean() > 0.85 and close[calm].mean() > 0.998
+    assert abs(got.mean() - want.mean()) < 5e-3 * want.mean()
+    # vertex by vertex on sampled paths (per-path entry point, which the dump above equals bit for bit)
+    g2, w2, close2, same_ids, calm2 = _path_parity(scene, oscene, cam, ocam, ob, 1500, 2, 50, 3, ob.TRAVERSE_GATED_BRUTE, h)
+    # dense field, depth 50: many short hops between spheres, so more ID sequences part ways under the stated
+    # direction error than in the sparse scene; the oracle's own perturbed run sets the bar
+    assert same_ids[calm2].mean() > _path_parity.id_floor, (same_ids[calm2].mean(), _path_parity.id_floor)
+    assert close2[calm2].mean() > _path_parity.id_floor - 0.001
+
+
+def test_render_kernel_paths_shells_against_oracle(rt, ob, earth_rgb8):
+    h = rt.gen_scene_shells(8)
+    scene, oscene = rt.Scene(h, [earth_rgb8]), ob.Scene(h, [earth_rgb8])
+    cam = rt.Camera.build([0, 0, 1], [0, 1.5, -5], 1.0, 0.1, 64, 64)
+    got, want, close, calm = _render_paths_against_oracle(scene, oscene, cam, _ocam(ob, cam), ob, 2, 50, 1, ob.TRAVERSE_GATED_BRUTE, h)
+    assert close[calm].mean() > 0.998 and (~calm).mean() > 0.1
+    assert abs(got[~calm].mean() - want[~calm].mean()) < 0.03 * want[~calm].mean()
+
+
+def test_shells_converged_image_psnr_against_reference_sampling(rt, ob, earth_rgb8):
+    """Earth map + nested dielectric shells, converged: the device against two independent oracle renders made with
+    the reference's own sampling (rejection loops, sequential stream) and its tree.  The near-root rule of
+    src/geometry.rs:115-120 (a refracted ray may re-hit the surface it starts on) shapes this image."""
+    h = rt.gen_scene_shells(8)
+    scene, oscene = rt.Scene(h, [earth_rgb8]), ob.Scene(h, [earth_rgb8])
+    cam = rt.Camera.build([0, 0, 1], [0, 1.5, -5], 1.0, 0.1, 64, 40)
+    ocam = _ocam(ob, cam)
+    spp = 1024
+    s, _ = scene.render(cam, spp, depth=50, seed=31)
+    a, _, _ = oscene.render(ocam, spp=spp, depth=50, seed=32, sampler=ob.SAMPLER_REFERENCE, traverse=ob.TRAVERSE_TREE)
+    b, _, _ = oscene.render(ocam, spp=spp, depth=50, seed=33, sampler=ob.SAMPLER_REFERENCE, traverse=ob.TRAVERSE_TREE)
+    floor = ob.psnr(a / spp, b / spp, peak=1.0)
+    ours = 0.5 * (ob.psnr(s / spp, a / spp, peak=1.0) + ob.psnr(s / spp, b / spp, peak=1.0))
+    assert ours > floor - 0.5, (ours, floor)
+    assert abs(s.mean() - a.mean()) / spp < 0.003
+
+
+def test_negative_radius_sphere_is_a_hollow_shell(rt, ob):
+    """A sphere with a negative radius has the same surface and an inward normal (the hollow-glass idiom).  The
+    reference's linear path handles it (the radius enters Sphere::intersect squared, src/geometry.rs:108); here it
+    also sits in the tree, whose boxes are built from |r|."""
+    rng = np.random.default_rng(4)
+    grey = rt.diffuse([.5, .5, .5])
+    items = [rt.sphere([0, 0, 0], 1.0, rt.dielectric(1.5)), rt.sphere([0, 0, 0], -0.9, rt.dielectric(1.5)),
+             rt.sphere([2.5, 0, 0], -0.7, grey), rt.sphere([0, -101, 0], 100.0, grey)]
+    items += [rt.sphere(list(rng.uniform(-4, 4, 3)), -0.3 if i % 2 else 0.3, grey) for i in range(40)]
+    h = rt.hittables(items)
+    o = rng.uniform(-5, 5, (8000, 3)).astype(np.float32)
+    d = rng.normal(size=(8000, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    want_ids, want_t, want_n, _ = ob.Scene(h).trace(o, d, ob.TRAVERSE_LINEAR)
+    for builder in ("sah", "lbvh"):
+        scene = rt.Scene(h, builder=builder)
+        ids, t, nrm = scene.trace_primary(o, d)
+        _check_hits(ids, t, nrm, want_ids, want_t, want_n)
+    assert (h["radius"][np.maximum(want_ids, 0)][want_ids >= 0] < 0).sum() > 150  # the inside-out spheres are being hit
+    cam = rt.Camera.build([0, 0, 0], [0, 1, -5], 1.0, 0.05, 64, 48)
+    scene, oscene = rt.Scene(h), ob.Scene(h)
+    got, want, close, calm = _render_paths_against_oracle(scene, oscene, cam, _ocam(ob, cam), ob, 2, 20, 2, ob.TRAVERSE_LINEAR, h)
+    assert close[calm].mean() > 0.998
+
+
+def test_far_origins_on_a_wide_sphere(rt, ob):
+    """Secondary rays start on the wide spheres, far outside the box of the tree's spheres: here a mirror dome of
+    radius 200 around a cluster of radius 1 sends nearly every camera ray back through the cluster.  The origin
+    widening of the f32 descent has to cover the rounding of such origins (it is sized from the wide spheres too)."""
+    rng = np.random.default_rng(6)
+    items = [rt.sphere([0, 0, 0], 200.0, rt.metal([0.9, 0.9, 0.9], 0.0))]
+    for _ in range(300):
+        c = rng.normal(size=3); c = c / np.linalg.norm(c) * rng.uniform(0.2, 1.0)
+        items.append(rt.sphere(list(c), 0.01, rt.diffuse(list(rng.uniform(0.2, 0.9, 3)))))
+    h = rt.hittables(items)
+    scene, oscene = rt.Scene(h), ob.Scene(h)
+    assert scene.info["n_wide"] == 1
+    # rays from the dome's surface aimed to graze the small spheres: the parity entry point sizes the widening
+    # from the origins it is given
+    n = 20000
+    o = rng.normal(size=(n, 3)); o = (o / np.linalg.norm(o, axis=1, keepdims=True) * 199.9).astype(np.float32)
+    k = rng.integers(1, len(items), n)
+    aim = h["centre"][k] + rng.normal(0, 0.008, (n, 3))
+    d = aim - o.astype(np.float64); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    ids, t, nrm = scene.trace_primary(o, d)
+    want_ids, want_t, want_n, _ = oscene.trace(o, d, ob.TRAVERSE_GATED_BRUTE)
+    _check_hits(ids, t, nrm, want_ids, want_t, want_n)
+    assert (want_ids > 0).mean() > 0.2
+    # the render kernels size it from the scene (wide spheres included) and the camera
+    cam = rt.Camera.build([0, 0, 0], [0.3, 0.2, -1.5], 1.5, 0.0, 64, 48)
+    n_px = 64 * 48
+    got = scene.render_paths(cam, 4, depth=6, seed=1).reshape(n_px * 4, 3).astype(np.float64)
+    pixel = np.repeat(np.arange(n_px, dtype=np.uint32), 4)
+    sample = np.tile(np.arange(4, dtype=np.uint32), n_px)
+    want = oscene.trace_paths(_ocam(ob, cam), pixel, sample, depth=6, seed=1, traverse=ob.TRAVERSE_GATED_BRUTE)
+    wi, _, _ = oscene.path_segments(_ocam(ob, cam), pixel, sample, depth=6, seed=1, traverse=ob.TRAVERSE_GATED_BRUTE, max_segments=6)
+    gi, _, _ = scene.path_segments(cam, pixel, sample, depth=6, seed=1, max_segments=6)
+    assert ((wi[:, 1:] > 0).any(axis=1)).mean() > 0.05  # rays coming back from the dome do hit the cluster
+    # the first bounce off the dome is exact to f64 rounding on both sides: its hit must be the same sphere
+    assert np.array_equal(gi[:, :2], wi[:, :2])
+    assert np.all(np.abs(got - want) <= 2e-3 * np.maximum(1.0, np.abs(want)), axis=1).mean() > 0.99
+
+
 def test_grid_scene_primary_hits(rt, ob):
     h = rt.gen_scene_grid(2, 48)  # 2305 spheres on the ground sphere
     scene, oscene = rt.Scene(h), ob.Scene(h)
@@ -389,6 +557,18 @@ def test_million_sphere_scene_primary_hits_and_render(rt, ob):
     want_ids, want_t, want_n, _ = ob.Scene(h).trace(o, d, ob.TRAVERSE_GATED_BRUTE)
     _check_hits(ids, t, nrm, want_ids, want_t, want_n)
     assert (want_ids > 0).sum() > 150  # small spheres, not only the ground
+    # 256 whole paths from the render kernel (tree in HBM, quantised nodes, assembly loop) against the oracle's
+    # scan over all million spheres
+    small = rt.Camera.build([0, 0, 0], [130, 40, 30], 1.0, 0.1, 16, 16)
+    oscene = ob.Scene(h)
+    got = scene.render_paths(small, 1, depth=50, seed=7).reshape(256, 3).astype(np.float64)
+    pxs = np.arange(256, dtype=np.uint32)
+    want = oscene.trace_paths(_ocam(ob, small), pxs, np.zeros(256, np.uint32), depth=50, seed=7, traverse=ob.TRAVERSE_GATED_BRUTE)
+    wi, _, _ = oscene.path_segments(_ocam(ob, small), pxs, np.zeros(256, np.uint32), depth=50, seed=7, traverse=ob.TRAVERSE_GATED_BRUTE, max_segments=12)
+    calm = ~np.any((wi >= 0) & (np.asarray(h["material"])[np.maximum(wi, 0)] == 2), axis=1)
+    close = np.all(np.abs(got - want) <= 2e-4 * np.maximum(1.0, np.abs(want)), axis=1)
+    assert calm.sum() > 200 and close[calm].mean() > 0.99, (calm.sum(), close[calm].mean())
+    assert (wi[:, 0] > 0).sum() > 60  # the camera rays do reach the small spheres
     # full-size render: finite, reproducible, sample ranges add up, schedules agree
     from raytracer_amd import _abi
     a, _ = scene.render(cam, 2, depth=50, seed=0, want_rgb8=False)
