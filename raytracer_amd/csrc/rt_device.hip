@@ -245,8 +245,16 @@ __device__ __forceinline__ Best closest_hit(const SceneDev& S, double ox, double
         A[a] = -(of[a] + S.eps) * i;
         B[a] = -(of[a] - S.eps) * i;
     }
+    // Culling to the parameter range [0, nearest hit so far] rests on a hit's parameter lying inside the interval in
+    // which the ray crosses the sphere's box.  That holds for unit directions (every path of a render: unit_f64).
+    // The parity entry point takes directions as given, and Sphere::intersect (src/geometry.rs:104-121) drops the
+    // quadratic's leading coefficient: with |d|^2 = 1 + e it answers for a sphere of radius^2 r^2 - e * |o - c|^2,
+    // whose hits may lie outside the box's interval (e = 1e-7 at 200 units is 4e-3 against r^2 = 9e-4).  So with
+    // GATE the descent follows the reference's LINE test (src/boundingvolume.rs:70-95): no clip at 0, no clip at the
+    // nearest hit; the gate and the quadratic then decide exactly as the reference does.
+    const float tmin = GATE ? -3.0e38f : 0.0f;
     float tmax = 3.0e38f;
-    if (best.k >= 0) tmax = float(best.t) * (1.0f + 4.0e-7f);
+    if (!GATE && best.k >= 0) tmax = float(best.t) * (1.0f + 4.0e-7f);
 
     int sp = 0;
     int32_t node = 0;
@@ -258,12 +266,12 @@ __device__ __forceinline__ Best closest_hit(const SceneDev& S, double ox, double
             float t0x = fmaf(q0.x, inv[0], A[0]), t1x = fmaf(q0.w, inv[0], B[0]);
             float t0y = fmaf(q0.y, inv[1], A[1]), t1y = fmaf(q1.x, inv[1], B[1]);
             float t0z = fmaf(q0.z, inv[2], A[2]), t1z = fmaf(q1.y, inv[2], B[2]);
-            float en0 = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
+            float en0 = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
             float ex0 = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
             float u0x = fmaf(q1.z, inv[0], A[0]), u1x = fmaf(q2.y, inv[0], B[0]);
             float u0y = fmaf(q1.w, inv[1], A[1]), u1y = fmaf(q2.z, inv[1], B[1]);
             float u0z = fmaf(q2.x, inv[2], A[2]), u1z = fmaf(q2.w, inv[2], B[2]);
-            float en1 = fmaxf(fmaxf(fminf(u0x, u1x), fminf(u0y, u1y)), fmaxf(fminf(u0z, u1z), 0.0f));
+            float en1 = fmaxf(fmaxf(fminf(u0x, u1x), fminf(u0y, u1y)), fmaxf(fminf(u0z, u1z), tmin));
             float ex1 = fminf(fminf(fmaxf(u0x, u1x), fmaxf(u0y, u1y)), fminf(fmaxf(u0z, u1z), tmax));
             const bool h0 = en0 <= ex0, h1 = en1 <= ex1;
             const int32_t c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
@@ -292,7 +300,7 @@ __device__ __forceinline__ Best closest_hit(const SceneDev& S, double ox, double
             if (GATE) ok = own_box_line_test_f64(s.x, s.y, s.z, s.w, ox, oy, oz, dx, dy, dz);
             if (ok && sphere_intersect_f64(s.x, s.y, s.z, s.w, ox, oy, oz, dx, dy, dz, &t)) {
                 consider(best, t, k, S.prim_id[k]);
-                tmax = float(best.t) * (1.0f + 4.0e-7f);
+                if (!GATE) tmax = float(best.t) * (1.0f + 4.0e-7f);
             }
             if (sp > 0) {
                 --sp;
@@ -688,7 +696,7 @@ struct Trav {
     float inv[3], A[3], B[3];
     float tmax;
     int32_t node;
-    int32_t sp;
+    uint32_t sp;  // LDS byte address of the next free slot of this lane's stack column (slots are BLOCK * 4 bytes apart)
     int32_t top;  // top of the stack lives in a register: a pop does not wait for LDS
     Best best;
 };
@@ -723,11 +731,11 @@ __device__ __forceinline__ bool sphere_candidate(const double4 s, int32_t k, int
 // QUANT: the boxes will come as grid indices q (Node32), plane = qbase + q * qstep: the grid is folded into the
 // per-ray factors, t = fma(q, qstep / d, (qbase - (o +- eps)) / d), the same count of roundings as with f32 planes.
 template <bool QUANT>
-__device__ __forceinline__ void trav_begin(const SceneDev& S, const Tables& Tb, const Path& p, Trav& T) {
+__device__ __forceinline__ void trav_begin(const SceneDev& S, const Tables& Tb, const Path& p, Trav& T, uint32_t slot1_addr) {
     T.best.t = 0.0;
     T.best.k = -1;
     T.best.id = 0x7fffffff;
-    T.sp = 1;
+    T.sp = slot1_addr;
     T.top = kLeafSentinel;
     for (int32_t i = 0; i < S.n_discs; ++i) {
         double t;
@@ -775,35 +783,35 @@ __device__ __forceinline__ void slab2(const Trav& T, float lo0x, float lo0y, flo
     *ex1 = fminf(fminf(fmaxf(u0x, u1x), fmaxf(u0y, u1y)), fminf(fmaxf(u0z, u1z), T.tmax));
 }
 
-// The stack keeps its top in T.top and the rest in LDS (stk[level * BLOCK], this lane's column).  A traversal
-// starts with sp == 1 and top == kLeafSentinel above slot 0, which the kernel fills with kLeafSentinel once and no
-// push ever writes (pushes store at sp >= 1): popping the empty stack yields the sentinel, which ends the
-// traversal, without a test of sp, and the lane does not pop again before trav_begin resets it.
+// The stack keeps its top in T.top and the rest in LDS (this lane's column: slot `level` at column base +
+// level * BLOCK * 4 bytes; T.sp is the byte address of the next free slot).  A traversal starts with T.sp at slot 1
+// and top == kLeafSentinel above slot 0, which the kernel fills with kLeafSentinel once and no push ever writes
+// (pushes store at slot >= 1): popping the empty stack yields the sentinel, which ends the traversal, without a
+// test of sp, and the lane does not pop again before trav_begin resets it.
+typedef __attribute__((address_space(3))) int32_t lds_i32;
 template <int BLOCK>
-__device__ __forceinline__ void pop(Trav& T, int32_t* stk) {
+__device__ __forceinline__ void pop(Trav& T) {
     T.node = T.top;
-    --T.sp;
-    T.top = stk[T.sp * BLOCK];
+    T.sp -= uint32_t(BLOCK * sizeof(int32_t));
+    T.top = *(lds_i32*)(uintptr_t)T.sp;
 }
 
 template <int BLOCK>
-__device__ __forceinline__ void descend(Trav& T, float en0, float ex0, float en1, float ex1, int32_t c0, int32_t c1,
-                                        int32_t* stk) {
+__device__ __forceinline__ void descend(Trav& T, float en0, float ex0, float en1, float ex1, int32_t c0, int32_t c1) {
     const bool h0 = en0 <= ex0, h1 = en1 <= ex1;
     const bool both = h0 && h1, swap = en1 < en0;
-    if (both) stk[T.sp * BLOCK] = T.top;
+    if (both) *(lds_i32*)(uintptr_t)T.sp = T.top;
     if (h0 || h1) {
         T.node = (h0 && !(h1 && swap)) ? c0 : c1;
         T.top = both ? (swap ? c0 : c1) : T.top;
-        T.sp += both ? 1 : 0;
+        T.sp += both ? uint32_t(BLOCK * sizeof(int32_t)) : 0u;
     } else {
-        pop<BLOCK>(T, stk);
+        pop<BLOCK>(T);
     }
 }
 
 template <bool LDS16, int BLOCK>
-__device__ __forceinline__ void inner_step(const SceneDev& S, const uint4* lds_q0, const uint4* lds_q1, Trav& T,
-                                           int32_t* stk) {
+__device__ __forceinline__ void inner_step(const SceneDev& S, const uint4* lds_q0, const uint4* lds_q1, Trav& T) {
     float en0, ex0, en1, ex1;
     int32_t c0, c1;
     if (LDS16) {
@@ -826,7 +834,7 @@ __device__ __forceinline__ void inner_step(const SceneDev& S, const uint4* lds_q
         c0 = int32_t(b.z);
         c1 = int32_t(b.w);
     }
-    descend<BLOCK>(T, en0, ex0, en1, ex1, c0, c1, stk);
+    descend<BLOCK>(T, en0, ex0, en1, ex1, c0, c1);
 }
 
 // LDS byte address of an object in dynamic shared memory
@@ -840,14 +848,14 @@ __device__ __forceinline__ uint32_t lds_address(const void* p) {
 // It is the same arithmetic as slab2/descend above (f16 bounds fed to v_fma_mix_f32, the lane's stack column in
 // LDS with its top in a register).  What the compiler's version of this loop spends and this one does not: about
 // sixteen register copies per turn for the loop-carried values, and a wait for the popped stack entry before the
-// next node can be fetched (here the pop's ds_read is only waited for together with the next node's data).
+// next node can be fetched.  Here every lane's next node is settled first (the selected child, or the stack top,
+// which is in a register), the exit test is made on it, and the next node's two reads are issued BEFORE the push /
+// pop bookkeeping, which runs while they are in flight; one taken branch per turn.
 // Fixed registers: v112-v127 and s88-s99 are scratch of this block (the 128-bit node halves need named registers,
 // inline-asm operands cannot name the dwords of a tuple).  EXEC is narrowed inside and restored before leaving.
 template <int BLOCK>
-__device__ __forceinline__ void inner_loop_lds16(Trav& T, uint32_t q0_addr, uint32_t q1_addr, uint32_t stk_addr,
-                                                 int32_t thr) {
+__device__ __forceinline__ void inner_loop_lds16(Trav& T, uint32_t q0_addr, uint32_t q1_addr, int32_t thr) {
     static_assert(BLOCK == 512 || BLOCK == 256, "stack column stride");
-    constexpr int kShift = (BLOCK == 512) ? 11 : 10;  // log2(BLOCK * sizeof(int32_t))
     // the "s" operands must BE scalar registers: the constraint alone does not move a value the compiler holds in a
     // vector register (it would print v13 into an s_ instruction)
     thr = __builtin_amdgcn_readfirstlane(max(thr, 1));  // with 0 the loop would never see "no lane left"
@@ -855,22 +863,24 @@ __device__ __forceinline__ void inner_loop_lds16(Trav& T, uint32_t q0_addr, uint
     q1_addr = uint32_t(__builtin_amdgcn_readfirstlane(int32_t(q1_addr)));
     int32_t lanes_on_inner;
     asm volatile(
-        "1:\n\t"
+        // which lanes stand on an inner node, and whether to run at all
         "v_cmp_lt_i32_e32 vcc, -1, %[node]\n\t"
+        "s_mov_b64 s[88:89], exec\n\t"
         "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
         "s_cmp_ge_i32 %[cnt], %[thr]\n\t"
-        "s_cbranch_scc1 3f\n\t"
+        "s_cbranch_scc1 4f\n\t"
         "s_cmp_eq_u32 %[cnt], 0\n\t"
-        "s_cbranch_scc1 2f\n\t"
+        "s_cbranch_scc1 9f\n\t"
         "v_cmp_lt_u32_e64 s[90:91], %[sentinel], %[node]\n\t"  // as unsigned: above the sentinel = a leaf
         "s_cmp_lg_u64 s[90:91], 0\n\t"
-        "s_cbranch_scc1 2f\n\t"
-        "3:\n\t"
-        "s_and_saveexec_b64 s[88:89], vcc\n\t"
+        "s_cbranch_scc1 9f\n\t"
+        "4:\n\t"
+        "s_mov_b64 exec, vcc\n\t"
         "v_lshl_add_u32 v112, %[node], 4, %[q0]\n\t"
         "v_lshl_add_u32 v113, %[node], 4, %[q1]\n\t"
         "ds_read_b128 v[120:123], v112\n\t"
         "ds_read_b128 v[124:127], v113\n\t"
+        "1:\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
         // child 0: v120 = lo.x lo.y | v121 = lo.z hi.x | v122 = hi.y hi.z
         "v_fma_mix_f32 v112, v120, %[ix], %[ax] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
@@ -917,25 +927,51 @@ __device__ __forceinline__ void inner_loop_lds16(Trav& T, uint32_t q0_addr, uint
         "s_andn2_b64 s[98:99], exec, s[98:99]\n\t"      // none
         "v_cndmask_b32_e64 %[node], v127, v126, s[94:95]\n\t"
         "v_cndmask_b32_e64 v112, v126, v127, s[94:95]\n\t"  // the other child, pushed where both are hit
-        "s_mov_b64 exec, s[96:97]\n\t"
-        "v_lshl_add_u32 v113, %[sp], %[shift], %[stk]\n\t"
-        "ds_write_b32 v113, %[top]\n\t"
-        "v_add_u32_e32 %[sp], 1, %[sp]\n\t"
+        "v_cndmask_b32_e64 %[node], %[node], %[top], s[98:99]\n\t"  // no child hit: go on with the stack top
+        // every lane's next node is known: decide whether the loop goes on, and if so start the next fetch before
+        // the stack is brought up to date
+        "v_cmp_lt_i32_e32 vcc, -1, %[node]\n\t"
+        "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
+        "s_cmp_ge_i32 %[cnt], %[thr]\n\t"
+        "s_cbranch_scc0 5f\n\t"
+        "6:\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "v_lshl_add_u32 v113, %[node], 4, %[q0]\n\t"
+        "v_lshl_add_u32 v114, %[node], 4, %[q1]\n\t"
+        "ds_read_b128 v[120:123], v113\n\t"
+        "ds_read_b128 v[124:127], v114\n\t"
+        "s_mov_b64 exec, s[96:97]\n\t"               // push
+        "ds_write_b32 %[sp], %[top]\n\t"
+        "v_add_u32_e32 %[sp], %[stride], %[sp]\n\t"
         "v_mov_b32_e32 %[top], v112\n\t"
-        "s_mov_b64 exec, s[98:99]\n\t"
-        "v_mov_b32_e32 %[node], %[top]\n\t"
-        "v_add_u32_e32 %[sp], -1, %[sp]\n\t"
-        "v_lshl_add_u32 v113, %[sp], %[shift], %[stk]\n\t"
-        "ds_read_b32 %[top], v113\n\t"
-        "s_mov_b64 exec, s[88:89]\n\t"
+        "s_mov_b64 exec, s[98:99]\n\t"               // pop
+        "v_subrev_u32_e32 %[sp], %[stride], %[sp]\n\t"
+        "ds_read_b32 %[top], %[sp]\n\t"
+        "s_mov_b64 exec, vcc\n\t"
         "s_branch 1b\n\t"
-        "2:\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
+        "5:\n\t"  // fewer than `thr` lanes go on: leave when none does, or when some lane of the wave waits at a leaf
+        "s_cmp_eq_u32 %[cnt], 0\n\t"
+        "s_cbranch_scc1 7f\n\t"
+        "s_mov_b64 exec, s[88:89]\n\t"
+        "v_cmp_lt_u32_e64 s[90:91], %[sentinel], %[node]\n\t"
+        "s_cmp_lg_u64 s[90:91], 0\n\t"
+        "s_cbranch_scc0 6b\n\t"
+        "7:\n\t"
+        "s_mov_b64 exec, s[96:97]\n\t"               // push
+        "ds_write_b32 %[sp], %[top]\n\t"
+        "v_add_u32_e32 %[sp], %[stride], %[sp]\n\t"
+        "v_mov_b32_e32 %[top], v112\n\t"
+        "s_mov_b64 exec, s[98:99]\n\t"               // pop
+        "v_subrev_u32_e32 %[sp], %[stride], %[sp]\n\t"
+        "ds_read_b32 %[top], %[sp]\n\t"
+        "9:\n\t"
+        "s_mov_b64 exec, s[88:89]\n\t"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
         : [node] "+v"(T.node), [sp] "+v"(T.sp), [top] "+v"(T.top), [cnt] "=&s"(lanes_on_inner)
         : [ix] "v"(T.inv[0]), [iy] "v"(T.inv[1]), [iz] "v"(T.inv[2]), [ax] "v"(T.A[0]), [ay] "v"(T.A[1]),
           [az] "v"(T.A[2]), [bx] "v"(T.B[0]), [by] "v"(T.B[1]), [bz] "v"(T.B[2]), [tmax] "v"(T.tmax),
-          [stk] "v"(stk_addr), [q0] "s"(q0_addr), [q1] "s"(q1_addr), [thr] "s"(thr), [sentinel] "s"(kLeafSentinel),
-          [shift] "n"(kShift)
+          [q0] "s"(q0_addr), [q1] "s"(q1_addr), [thr] "s"(thr), [sentinel] "s"(kLeafSentinel),
+          [stride] "s"(uint32_t(BLOCK * sizeof(int32_t)))
         : "memory", "vcc", "scc", "v112", "v113", "v114", "v115", "v116", "v117",
           "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "s88", "s89", "s90", "s91",
           "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
@@ -943,10 +979,10 @@ __device__ __forceinline__ void inner_loop_lds16(Trav& T, uint32_t q0_addr, uint
 
 // The same loop for the tree in HBM (Node32: boxes as 16-bit grid indices, the grid folded into T.inv / T.A / T.B
 // by trav_begin<true>): two 16-byte global loads per node, 12 conversions + 12 FMAs instead of the 12 mixed FMAs.
+// The node's byte offset (index * 32) is formed in 32 bits: rt_scene_create admits at most 2^26 spheres in a tree.
 template <int BLOCK>
-__device__ __forceinline__ void inner_loop_hbm(Trav& T, const Node32* nodes32, uint32_t stk_addr, int32_t thr) {
+__device__ __forceinline__ void inner_loop_hbm(Trav& T, const Node32* nodes32, int32_t thr) {
     static_assert(BLOCK == 512 || BLOCK == 256, "stack column stride");
-    constexpr int kShift = (BLOCK == 512) ? 11 : 10;  // log2(BLOCK * sizeof(int32_t))
     // scalar registers for the "s" operands, as in inner_loop_lds16
     thr = __builtin_amdgcn_readfirstlane(max(thr, 1));
     const uint64_t base_bits = reinterpret_cast<uint64_t>(nodes32);
@@ -954,34 +990,36 @@ __device__ __forceinline__ void inner_loop_hbm(Trav& T, const Node32* nodes32, u
                           (uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int32_t(uint32_t(base_bits >> 32))))) << 32);
     int32_t lanes_on_inner;
     asm volatile(
-        "1:\n\t"
+        // which lanes stand on an inner node, and whether to run at all
         "v_cmp_lt_i32_e32 vcc, -1, %[node]\n\t"
+        "s_mov_b64 s[88:89], exec\n\t"
         "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
         "s_cmp_ge_i32 %[cnt], %[thr]\n\t"
-        "s_cbranch_scc1 3f\n\t"
+        "s_cbranch_scc1 4f\n\t"
         "s_cmp_eq_u32 %[cnt], 0\n\t"
-        "s_cbranch_scc1 2f\n\t"
+        "s_cbranch_scc1 9f\n\t"
         "v_cmp_lt_u32_e64 s[90:91], %[sentinel], %[node]\n\t"  // as unsigned: above the sentinel = a leaf
         "s_cmp_lg_u64 s[90:91], 0\n\t"
-        "s_cbranch_scc1 2f\n\t"
-        "3:\n\t"
-        "s_and_saveexec_b64 s[88:89], vcc\n\t"
+        "s_cbranch_scc1 9f\n\t"
+        "4:\n\t"
+        "s_mov_b64 exec, vcc\n\t"
         "v_lshlrev_b32_e32 v112, 5, %[node]\n\t"
         "global_load_dwordx4 v[120:123], v112, %[base]\n\t"
         "global_load_dwordx4 v[124:127], v112, %[base] offset:16\n\t"
+        "1:\n\t"
         "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
         // child 0: v120 = lo.x lo.y | v121 = lo.z hi.x | v122 = hi.y hi.z as 16-bit grid indices
         "v_cvt_f32_u32_sdwa v112, v120 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
-        "v_fma_f32 v112, v112, %[ix], %[ax]\n\t"
         "v_cvt_f32_u32_sdwa v113, v121 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-        "v_fma_f32 v113, v113, %[ix], %[bx]\n\t"
         "v_cvt_f32_u32_sdwa v114, v120 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-        "v_fma_f32 v114, v114, %[iy], %[ay]\n\t"
         "v_cvt_f32_u32_sdwa v115, v122 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
-        "v_fma_f32 v115, v115, %[iy], %[by]\n\t"
         "v_cvt_f32_u32_sdwa v116, v121 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
-        "v_fma_f32 v116, v116, %[iz], %[az]\n\t"
         "v_cvt_f32_u32_sdwa v117, v122 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+        "v_fma_f32 v112, v112, %[ix], %[ax]\n\t"
+        "v_fma_f32 v113, v113, %[ix], %[bx]\n\t"
+        "v_fma_f32 v114, v114, %[iy], %[ay]\n\t"
+        "v_fma_f32 v115, v115, %[iy], %[by]\n\t"
+        "v_fma_f32 v116, v116, %[iz], %[az]\n\t"
         "v_fma_f32 v117, v117, %[iz], %[bz]\n\t"
         "v_min_f32_e32 v118, v112, v113\n\t"
         "v_max_f32_e32 v112, v112, v113\n\t"
@@ -995,16 +1033,16 @@ __device__ __forceinline__ void inner_loop_hbm(Trav& T, const Node32* nodes32, u
         "v_min3_f32 v119, v112, v114, v116\n\t"   // exit parameter of child 0
         // child 1: v123 = lo.x lo.y | v124 = lo.z hi.x | v125 = hi.y hi.z
         "v_cvt_f32_u32_sdwa v112, v123 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
-        "v_fma_f32 v112, v112, %[ix], %[ax]\n\t"
         "v_cvt_f32_u32_sdwa v113, v124 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-        "v_fma_f32 v113, v113, %[ix], %[bx]\n\t"
         "v_cvt_f32_u32_sdwa v114, v123 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-        "v_fma_f32 v114, v114, %[iy], %[ay]\n\t"
         "v_cvt_f32_u32_sdwa v115, v125 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
-        "v_fma_f32 v115, v115, %[iy], %[by]\n\t"
         "v_cvt_f32_u32_sdwa v116, v124 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
-        "v_fma_f32 v116, v116, %[iz], %[az]\n\t"
         "v_cvt_f32_u32_sdwa v117, v125 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+        "v_fma_f32 v112, v112, %[ix], %[ax]\n\t"
+        "v_fma_f32 v113, v113, %[ix], %[bx]\n\t"
+        "v_fma_f32 v114, v114, %[iy], %[ay]\n\t"
+        "v_fma_f32 v115, v115, %[iy], %[by]\n\t"
+        "v_fma_f32 v116, v116, %[iz], %[az]\n\t"
         "v_fma_f32 v117, v117, %[iz], %[bz]\n\t"
         "v_min_f32_e32 v122, v112, v113\n\t"
         "v_max_f32_e32 v112, v112, v113\n\t"
@@ -1027,36 +1065,61 @@ __device__ __forceinline__ void inner_loop_hbm(Trav& T, const Node32* nodes32, u
         "s_andn2_b64 s[98:99], exec, s[98:99]\n\t"      // none
         "v_cndmask_b32_e64 %[node], v127, v126, s[94:95]\n\t"
         "v_cndmask_b32_e64 v112, v126, v127, s[94:95]\n\t"  // the other child, pushed where both are hit
-        "s_mov_b64 exec, s[96:97]\n\t"
-        "v_lshl_add_u32 v113, %[sp], %[shift], %[stk]\n\t"
-        "ds_write_b32 v113, %[top]\n\t"
-        "v_add_u32_e32 %[sp], 1, %[sp]\n\t"
+        "v_cndmask_b32_e64 %[node], %[node], %[top], s[98:99]\n\t"  // no child hit: go on with the stack top
+        // every lane's next node is known: decide whether the loop goes on, and if so start the next fetch before
+        // the stack is brought up to date
+        "v_cmp_lt_i32_e32 vcc, -1, %[node]\n\t"
+        "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
+        "s_cmp_ge_i32 %[cnt], %[thr]\n\t"
+        "s_cbranch_scc0 5f\n\t"
+        "6:\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "v_lshlrev_b32_e32 v113, 5, %[node]\n\t"
+        "global_load_dwordx4 v[120:123], v113, %[base]\n\t"
+        "global_load_dwordx4 v[124:127], v113, %[base] offset:16\n\t"
+        "s_mov_b64 exec, s[96:97]\n\t"               // push
+        "ds_write_b32 %[sp], %[top]\n\t"
+        "v_add_u32_e32 %[sp], %[stride], %[sp]\n\t"
         "v_mov_b32_e32 %[top], v112\n\t"
-        "s_mov_b64 exec, s[98:99]\n\t"
-        "v_mov_b32_e32 %[node], %[top]\n\t"
-        "v_add_u32_e32 %[sp], -1, %[sp]\n\t"
-        "v_lshl_add_u32 v113, %[sp], %[shift], %[stk]\n\t"
-        "ds_read_b32 %[top], v113\n\t"
-        "s_mov_b64 exec, s[88:89]\n\t"
+        "s_mov_b64 exec, s[98:99]\n\t"               // pop
+        "v_subrev_u32_e32 %[sp], %[stride], %[sp]\n\t"
+        "ds_read_b32 %[top], %[sp]\n\t"
+        "s_mov_b64 exec, vcc\n\t"
         "s_branch 1b\n\t"
-        "2:\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
+        "5:\n\t"  // fewer than `thr` lanes go on: leave when none does, or when some lane of the wave waits at a leaf
+        "s_cmp_eq_u32 %[cnt], 0\n\t"
+        "s_cbranch_scc1 7f\n\t"
+        "s_mov_b64 exec, s[88:89]\n\t"
+        "v_cmp_lt_u32_e64 s[90:91], %[sentinel], %[node]\n\t"
+        "s_cmp_lg_u64 s[90:91], 0\n\t"
+        "s_cbranch_scc0 6b\n\t"
+        "7:\n\t"
+        "s_mov_b64 exec, s[96:97]\n\t"               // push
+        "ds_write_b32 %[sp], %[top]\n\t"
+        "v_add_u32_e32 %[sp], %[stride], %[sp]\n\t"
+        "v_mov_b32_e32 %[top], v112\n\t"
+        "s_mov_b64 exec, s[98:99]\n\t"               // pop
+        "v_subrev_u32_e32 %[sp], %[stride], %[sp]\n\t"
+        "ds_read_b32 %[top], %[sp]\n\t"
+        "9:\n\t"
+        "s_mov_b64 exec, s[88:89]\n\t"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
         : [node] "+v"(T.node), [sp] "+v"(T.sp), [top] "+v"(T.top), [cnt] "=&s"(lanes_on_inner)
         : [ix] "v"(T.inv[0]), [iy] "v"(T.inv[1]), [iz] "v"(T.inv[2]), [ax] "v"(T.A[0]), [ay] "v"(T.A[1]),
           [az] "v"(T.A[2]), [bx] "v"(T.B[0]), [by] "v"(T.B[1]), [bz] "v"(T.B[2]), [tmax] "v"(T.tmax),
-          [stk] "v"(stk_addr), [base] "s"(base), [thr] "s"(thr), [sentinel] "s"(kLeafSentinel),
-          [shift] "n"(kShift)
+          [base] "s"(base), [thr] "s"(thr), [sentinel] "s"(kLeafSentinel),
+          [stride] "s"(uint32_t(BLOCK * sizeof(int32_t)))
         : "memory", "vcc", "scc", "v112", "v113", "v114", "v115", "v116", "v117",
           "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "s88", "s89", "s90", "s91",
           "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
 }
 
 template <bool LDS16, int BLOCK>
-__device__ __forceinline__ void leaf_step(const Tables& Tb, const Path& p, Trav& T, int32_t* stk) {
+__device__ __forceinline__ void leaf_step(const Tables& Tb, const Path& p, Trav& T) {
     const int32_t k = ~T.node;
     const bool better = sphere_candidate(Tb.sph[k], k, Tb.prim_id[k], p, true, T.best);
     T.tmax = better ? float(T.best.t) * (1.0f + 4.0e-7f) : T.tmax;
-    pop<BLOCK>(T, stk);
+    pop<BLOCK>(T);
 }
 
 // MODE selects a diagnostic build of the same kernel:
@@ -1128,7 +1191,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     p.pixel = 0; p.sample = 0; p.bounce = 0;
     Trav T;
     T.node = kLeafSentinel;
-    T.sp = 1;
+    T.sp = 0;
     T.top = kLeafSentinel;
     T.tmax = 0.0f;
     T.best.t = 0.0; T.best.k = -1; T.best.id = 0;
@@ -1139,7 +1202,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     float ar = 0.0f, ag = 0.0f, ab = 0.0f;
     const int trav_threshold = int(P.trav_threshold), inner_threshold = int(P.inner_threshold);
     const int leave_threshold = int(P.leave_threshold);
-    const uint32_t q0_addr = lds_address(lds_q0), q1_addr = lds_address(lds_q1), stk_addr = lds_address(stk);
+    const uint32_t q0_addr = lds_address(lds_q0), q1_addr = lds_address(lds_q1);
+    const uint32_t slot1_addr = lds_address(stk) + uint32_t(BLOCK * sizeof(int32_t));
     const uint32_t prio_inner = (P.flags >> 16) & 3u, prio_leaf = (P.flags >> 18) & 3u, prio_shade = (P.flags >> 20) & 3u;
     const bool prio_used = (P.flags >> 16) & 63u;
 
@@ -1202,7 +1266,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                 } else if (!scatter_part(P, p, sf, r)) {
                     alive = false;  // bounded fuzz loop gave up: the path contributes nothing
                 }
-                if (alive) trav_begin<!LDS16>(S, Tb, p, T);
+                if (alive) trav_begin<!LDS16>(S, Tb, p, T, slot1_addr);
             }
         }
         if (TIMING) cyc[0] += cycle_stamp() - t_shade;
@@ -1224,22 +1288,22 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
             if (TIMING) cyc[1] += t_inner - t_head;
             if (prio_used) set_wave_priority(prio_inner);
             if (LDS16 && !STATS) {
-                inner_loop_lds16<BLOCK>(T, q0_addr, q1_addr, stk_addr, run_threshold);
+                inner_loop_lds16<BLOCK>(T, q0_addr, q1_addr, run_threshold);
             } else if (!STATS) {
-                inner_loop_hbm<BLOCK>(T, S.nodes32, stk_addr, run_threshold);
+                inner_loop_hbm<BLOCK>(T, S.nodes32, run_threshold);
             } else {
                 for (;;) {
                     const int n_inner = int(__popcll(__ballot(T.node >= 0)));
                     if (n_inner < run_threshold && (n_inner == 0 || __any(T.node < 0 && T.node != kLeafSentinel))) break;
                     if (STATS) { st[0]++; if (T.node >= 0) st[1]++; }
-                    if (T.node >= 0) inner_step<LDS16, BLOCK>(S, lds_q0, lds_q1, T, stk);
+                    if (T.node >= 0) inner_step<LDS16, BLOCK>(S, lds_q0, lds_q1, T);
                 }
             }
             const uint64_t t_leaf = TIMING ? cycle_stamp() : 0;
             if (TIMING) cyc[2] += t_leaf - t_inner;
             if (prio_used) set_wave_priority(prio_leaf);
             if (STATS && __any(T.node < 0 && T.node != kLeafSentinel)) { st[2]++; if (T.node < 0 && T.node != kLeafSentinel) st[3]++; }
-            if (T.node < 0 && T.node != kLeafSentinel) leaf_step<LDS16, BLOCK>(Tb, p, T, stk);
+            if (T.node < 0 && T.node != kLeafSentinel) leaf_step<LDS16, BLOCK>(Tb, p, T);
             if (TIMING) cyc[3] += cycle_stamp() - t_leaf;
         }
     }
