@@ -98,20 +98,32 @@ def main():
     begin, end = rt.sample_shard(total_spp, rank, world)
     kernel_ms = []
 
+    scene.reserve(cam, end - begin, sample_begin=begin)  # partial-sum buffer sized once: the timed calls only enqueue
+
     def step(timed):
+        """raytracer_amd.shard.render_step with the GPU pieces plugged in (the CPU tests plug in the oracle)."""
         stream = torch.cuda.current_stream().cuda_stream
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-        scene.render_device(cam, d_sum.data_ptr(), begin, end, DEPTH, SEED, stream=stream, flags=args.kernel_flags)
-        ev1.record()
-        if world > 1 and rehearse:
-            host = d_sum.cpu()
-            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
-            d_sum.copy_(host)
-        elif world > 1:
-            dist.reduce(d_sum, dst=0, op=dist.ReduceOp.SUM)
-        if rank == 0:
-            scene.finalize_device(d_sum.data_ptr(), n_pixels, total_spp, d_rgb.data_ptr(), stream=stream)
+
+        def render_range(b, e):
+            ev0.record()  # torch's current stream is the one the kernel is launched on
+            scene.render_device(cam, d_sum.data_ptr(), b, e, DEPTH, SEED, stream=stream, flags=args.kernel_flags)
+            ev1.record()
+            return d_sum
+
+        def reduce_to_root(t):
+            if rehearse:
+                host = t.cpu()
+                dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+                t.copy_(host)
+            else:
+                dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+
+        def finalize(t, spp):
+            scene.finalize_device(t.data_ptr(), n_pixels, spp, d_rgb.data_ptr(), stream=stream)
+            return d_rgb
+
+        rt.render_step(render_range, reduce_to_root, finalize, total_spp, rank, world)
         if timed:
             kernel_ms.append((ev0, ev1))
 
@@ -137,11 +149,19 @@ def main():
     if rank == 0:
         paths_per_step = n_pixels * total_spp
         value = paths_per_step * args.steps / elapsed / 1e6
+        # segments per path, counted by the device that is being rated: one launch of the instrumented build of the
+        # same kernel, outside the timed region (every shade visit of a live path closes one segment)
+        from raytracer_amd import _abi
+        import numpy as np
+        scene.render_device(cam, d_sum.data_ptr(), begin, end, DEPTH, SEED, stream=torch.cuda.current_stream().cuda_stream,
+                            flags=_abi.RT_RENDER_STATS)
+        torch.cuda.synchronize()
+        st = np.zeros(8, dtype=np.uint64)
+        _abi.check(_abi.lib.rt_debug_render_stats(scene.handle, st.ctypes.data))
+        seg = round((float(st[5]) - float(st[6])) / (n_pixels * (end - begin)), 4)
         base = cpu_baseline(hittables, args.cpu_seconds) if (args.cpu_seconds > 0 and world == 1) else None
-        # segments per path of this workload: counted by the CPU leg when it runs, else the value it counts
-        # (a property of scene, camera, depth and sampling rule, not of the machine)
-        seg = base["segments_per_path"] if base else roofline.C2_SEGMENTS_PER_PATH
         fpp = roofline.flops_per_path(len(hittables), seg)
+        traffic = roofline.measured_traffic_bytes()
         achieved = (n_pixels * (end - begin)) * fpp / (render_ms * 1e-3) / 1e12 if render_ms > 0 else 0.0
         img_mean = float(d_rgb.float().mean().item())
         line = {
@@ -153,9 +173,13 @@ def main():
                        "paths_per_step": paths_per_step, "parallelism": "sample-split x%d + RCCL sum-reduce" % world,
                        "image_mean_u8": round(img_mean, 3)},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": roofline.PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / roofline.PEAK_FP32_TFLOPS, 5), "traffic": None,
-                         "kernel": "render_kernel_ws<true, 512, false> (+ combine_kernel, 0.02 ms)", "kernel_ms": round(render_ms, 3),
+                         "frac": round(achieved / roofline.PEAK_FP32_TFLOPS, 5),
+                         "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_source": traffic["source"] if traffic else None,
+                         "kernel": "render_kernel_ws<true, 512, 0> (+ combine_kernel, 0.03 ms)", "kernel_ms": round(render_ms, 3),
+                         "kernel_ms_source": "HIP events on the launching stream around rt_render_device, mean of the timed steps",
                          "algorithmic_flops_per_path": round(fpp, 1), "segments_per_path": seg,
+                         "segments_per_path_source": "device: RT_RENDER_STATS launch of the same kernel outside the timed region"
+                                                     + ("; CPU oracle counts %.4f" % base["segments_per_path"] if base else ""),
                          "note": "FP32 vector-ALU bound (BVH and spheres are cache resident, no dense contraction so no MFMA); "
                                  "algorithmic flops = reference arithmetic with a 2*ceil(log2 N)-box traversal model"},
         }

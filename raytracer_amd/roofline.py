@@ -13,7 +13,7 @@ F_ACCUMULATE = 3  # per path
 NODE_BYTES = 32   # one box = 6 f32 + 2 indices
 SPHERE_BYTES = 16
 
-PEAK_FP32_TFLOPS = 157.3  # MI355X vector FP32 (packed v_pk_fma_f32 rate); the non-packed ceiling is 78.6
+PEAK_FP32_TFLOPS = 157.3  # MI355X vector FP32: 1024 SIMDs x 32 lanes x 2 flop (plain v_fma_f32, one wave64 instruction per 2 cycles) x 2.4 GHz
 PEAK_HBM_GBS = 8000.0
 
 
@@ -27,6 +27,31 @@ def flops_per_path(n_spheres, segments_per_path):
 
 def bytes_per_segment(n_spheres):
     return 2 * math.ceil(math.log2(max(n_spheres, 2))) * NODE_BYTES + SPHERE_BYTES
+
+
+def measured_traffic_bytes(summary_path=None):
+    """HBM bytes per launch of the bench workload's render kernel (+ combine_kernel), from the committed summary of
+    separate `rocprofv3 --pmc` passes over `bench.py --steps 1 --warmup 0` (scripts/pmc_passes.sh): FETCH_SIZE and
+    WRITE_SIZE are in KiB, and on gfx950 FETCH_SIZE reports half of the bytes read, hence the factor 2.  Returns
+    {"bytes_per_launch", "source"} or None when no summary is there."""
+    import glob
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    paths = [summary_path] if summary_path else sorted(glob.glob(os.path.join(root, "profiles", "r*", "bench_pmc_summary.txt")))
+    for path in reversed(paths):
+        vals = {}
+        try:
+            for line in open(path):
+                parts = line.split()
+                if len(parts) == 2:
+                    vals[parts[0]] = float(parts[1])
+        except OSError:
+            continue
+        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+            return {"bytes_per_launch": int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024),
+                    "source": os.path.relpath(path, root) + ": (2 x FETCH_SIZE + WRITE_SIZE) KiB, one launch"}
+    return None
 
 
 # Mean segments per path of the bench workload (random spheres seed 1, default camera, depth 50), as counted by the

@@ -17,17 +17,18 @@ def sample_shard(spp, rank, world_size):
     return (rank * spp) // world_size, ((rank + 1) * spp) // world_size
 
 
-def sharded_sum(render_range, spp, rank, world_size, reduce_to_root):
-    """Runs one rank's share and reduces.
+def render_step(render_range, reduce_to_root, finalize, spp, rank, world_size):
+    """One step of the multi-rank render: this rank's share, the one sum-reduce, rank 0's finalise.
 
-    render_range(begin, end) -> this rank's sum image (any tensor type; a rank
-    whose range is empty gets render_range(b, b) and must return zeros);
-    reduce_to_root(t) sums t over ranks into rank 0's t (e.g.
-    torch.distributed.reduce).  Returns the local tensor: the full-sample sum on
-    rank 0.
+    render_range(begin, end) -> this rank's sum image (any tensor type; a rank whose range is empty gets
+    render_range(b, b) and must return zeros); reduce_to_root(t) sums t over ranks into rank 0's t
+    (torch.distributed.reduce over RCCL, or over gloo in the CPU tests); finalize(t, spp) turns rank 0's
+    full-sample sum into the image (mean, gamma, quantise) and is called on rank 0 only.  bench.py and the
+    world-size-2 tests run this same function.  Returns (local tensor, what finalize returned or None).
     """
     begin, end = sample_shard(spp, rank, world_size)
     local = render_range(begin, end)
     if world_size > 1:
         reduce_to_root(local)
-    return local
+    image = finalize(local, spp) if rank == 0 else None
+    return local, image

@@ -32,3 +32,30 @@ def test_bench_line_has_the_agreed_shape():
         assert key in cb, key
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
     assert d["value"] > 100 * cb["value"]  # sanity: three orders of magnitude are expected, two must be there
+
+
+@pytest.mark.gpu
+def test_two_rank_step_gives_the_single_render(rt):
+    """bench.py --gpus 2 as the driver starts it (torch.distributed.run, one process per rank), with both ranks on the
+    GPUs that are there and the reduce over gloo (BENCH_REHEARSE=1): the step bench.py times — each rank's sample
+    range, the sum-reduce to rank 0, rank 0's finalise — must produce the image of one 200-sample render."""
+    import socket
+
+    import numpy as np
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["paths_per_step"] == 1920 * 1080 * 200 and "REHEARSAL" in d["data"]
+    scene = rt.Scene(rt.gen_scene(1))
+    _, q = scene.render(rt.default_camera(1920, 1080), 200, depth=50, seed=0, want_sum=False)
+    # two 100-sample sums added instead of one 200-sample sum: f32 rounding may move a channel by one step
+    assert abs(d["config"]["image_mean_u8"] - float(np.mean(q))) < 0.01

@@ -32,7 +32,7 @@ def _worker(rank, world, port, out_path):
     import torch.distributed as dist
 
     import oracle_binding as ob
-    from raytracer_amd.shard import sharded_sum
+    from raytracer_amd.shard import render_step
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     scene = ob.Scene(ob.gen_scene(1))
@@ -45,10 +45,13 @@ def _worker(rank, world, port, out_path):
         s, _, _ = scene.render(cam, spp=e - b, depth=10, seed=7, sample_begin=b, threads=1)
         return torch.from_numpy(s)
 
-    total = sharded_sum(render_range, spp, rank, world, lambda t: dist.reduce(t, dst=0, op=dist.ReduceOp.SUM))
+    total, image = render_step(render_range, lambda t: dist.reduce(t, dst=0, op=dist.ReduceOp.SUM),
+                               lambda t, n: ob.finalize(t.numpy(), n), spp, rank, world)
     dist.barrier()
+    assert (image is None) == (rank != 0)  # only rank 0 finalises
     if rank == 0:
         np.save(out_path, total.numpy())
+        np.save(out_path + ".rgb8.npy", image)
     dist.destroy_process_group()
 
 
@@ -66,3 +69,4 @@ def test_two_rank_gloo_reduce_equals_single_rank(ob, tmp_path):
     want, _, _ = scene.render(cam, spp=5, depth=10, seed=7, threads=1)
     assert np.allclose(got, want, rtol=1e-12, atol=0)
     assert np.array_equal(ob.finalize(got, 5), ob.finalize(want, 5))
+    assert np.array_equal(np.load(out + ".rgb8.npy"), ob.finalize(want, 5))  # what rank 0's finalise step produced
