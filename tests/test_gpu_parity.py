@@ -737,3 +737,33 @@ def test_render_multi_splits_samples_over_scene_handles(rt, scene1):
     assert np.array_equal(one, whole) and np.array_equal(q_one, q_whole)
     with pytest.raises(rt.RtError):
         rt.render_multi(scenes, cam, 2)  # fewer samples than devices
+
+
+def test_render_device_only_enqueues_once_reserved(rt, scene1):
+    """After rt_scene_reserve a render call allocates nothing and waits for nothing: it returns while the kernel is
+    still running (the stream is not done when the call is back), twice in a row on a stream of the caller's."""
+    import ctypes as C
+    import time
+
+    import hip_mem
+    from raytracer_amd import _abi
+
+    cam = rt.default_camera(1920, 1080)
+    spp = 100  # ~12 ms of kernel; the call itself takes tens of microseconds
+    scene1.reserve(cam, spp)
+    stream = hip_mem.Stream()
+    a, b = hip_mem.DeviceArray(1920 * 1080 * 3), hip_mem.DeviceArray(1920 * 1080 * 3)
+    o = rt.Scene.opts(0, spp, 50, 0)
+    back = []
+    for buf in (a, b):
+        t0 = time.perf_counter()
+        _abi.check(_abi.lib.rt_render_device(scene1.handle, C.byref(cam.c), C.byref(o), buf.ptr, stream.handle))
+        back.append((time.perf_counter() - t0, stream.done()))
+    stream.synchronize()
+    assert stream.done()
+    assert not back[0][1] and not back[1][1], back   # both calls came back before their kernels had finished
+    assert max(t for t, _ in back) < 5e-3, back       # and well inside one kernel's duration
+    ra, rb = a.numpy(), b.numpy()
+    assert np.array_equal(ra, rb) and np.isfinite(ra).all()
+    want, _ = scene1.render(cam, spp, depth=50, seed=0, want_rgb8=False)
+    assert np.array_equal(ra.reshape(1080, 1920, 3), want)
