@@ -183,6 +183,21 @@ int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_render_opts
  * rt_render_device neither allocates nor waits.  No counterpart in the reference (it has no device). */
 int rt_scene_reserve(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts);
 
+/* rt_render_device for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same result; the
+ * work counter and the partial sums of a chunked render live in a fixed array of RT_NOALLOC_SCRATCH_BYTES of
+ * device memory that is part of the library's code object (one copy per GPU, held until the process ends), so the
+ * call makes no hipMalloc / hipFree.  Limits: with samples_per_item given, the partial sums
+ * (chunks * horiz_res * vert_res * 12 bytes, chunks > 1) must fit RT_NOALLOC_SCRATCH_BYTES - 256, else RT_ERR_LIMIT;
+ * with samples_per_item = 0 the library uses min(the chunk count of rt_render_chunk, what fits, at least 1), i.e.
+ * samples per item = ceil(spp / that count), so large frames are summed in fewer, longer chunks than
+ * rt_render_device would use (same image up to f32 summation order).  Every call on a GPU uses that GPU's one array:
+ * calls that overlap on one GPU — different scene handles on different streams — race; calls through one handle
+ * are ordered like all renders of a handle.  RT_RENDER_STATS / RT_RENDER_TIMING are refused here. */
+#define RT_NOALLOC_SCRATCH_BYTES (64u * 1024u * 1024u)
+int rt_render_device_noalloc(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, float* d_sum_rgb,
+                             void* stream);
+
 /* Measurement aid: phase counters of the last RT_RENDER_STATS render on this scene:
  * {inner-node turns*64, lanes in them, leaf turns*64, lanes, shade turns*64, lanes shading or
  * regenerating, lanes regenerating, descent-loop turns*64}; after an RT_RENDER_TIMING render the same

@@ -19,6 +19,7 @@ RT_SHAPE_SPHERE, RT_SHAPE_DISC = 0, 1
 RT_MAT_DIFFUSE, RT_MAT_METAL, RT_MAT_DIELECTRIC, RT_MAT_TEXTUREMAP, RT_MAT_EMITTER = 0, 1, 2, 3, 4
 RT_RENDER_ACCUMULATE, RT_RENDER_KERNEL_LOCKSTEP, RT_RENDER_KERNEL_NO_LDS_SCENE = 1, 2, 4
 RT_RENDER_STATS, RT_RENDER_TIMING = 8, 16
+RT_NOALLOC_SCRATCH_BYTES = 64 * 1024 * 1024
 
 # rt_hittable as a numpy record (same layout as the C struct), so that a million
 # hittables are one array and not a million Python objects.
@@ -120,6 +121,7 @@ PROTOTYPES = {
     "rt_scene_destroy": (None, [_vp]),
     "rt_scene_get_info": (_i, [_vp, C.POINTER(rt_scene_info)]),
     "rt_render_device": (_i, [_vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts), _vp, _vp]),
+    "rt_render_device_noalloc": (_i, [_vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts), _vp, _vp]),
     "rt_scene_reserve": (_i, [_vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts)]),
     "rt_debug_render_stats": (_i, [_vp, _vp]),
     "rt_debug_render_paths": (_i, [_vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts), _vp]),

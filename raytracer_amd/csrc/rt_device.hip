@@ -1426,6 +1426,11 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const float* __restric
     rgb8[g] = q;
 }
 
+// Scratch of rt_render_device_noalloc: the first 256 bytes are the work counter (and the words of the diagnostic
+// builds), the rest holds the partial sums of chunked renders.  One copy per GPU the library runs on, for the life of
+// the process.  In host code this name is only a handle for hipGetSymbolAddress, never a device address.
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+
 }  // namespace rt
 
 // =====================================================================
@@ -1591,7 +1596,7 @@ int check_render_args(const rt_scene* scene, const rt_camera* cam, const rt_rend
     return RT_OK;
 }
 
-RenderParams make_params(const rt_camera& cam, const rt_render_opts& o) {
+RenderParams make_params(const rt_camera& cam, const rt_render_opts& o, uint32_t max_chunks = 64) {
     RenderParams P;
     P.sample_begin = o.sample_begin;
     P.sample_end = o.sample_end;
@@ -1610,7 +1615,7 @@ RenderParams make_params(const rt_camera& cam, const rt_render_opts& o) {
         P.chunk_spp = std::min<uint32_t>(o.samples_per_item, spp);
     } else {
         const uint64_t want_items = 13000000, px = std::max<uint32_t>(P.n_pixels, 1);  // pixel chunks = 64 x tile items
-        uint32_t chunks = uint32_t(std::min<uint64_t>(std::max<uint64_t>(1, (want_items + px / 2) / px), 64));
+        uint32_t chunks = uint32_t(std::min<uint64_t>(std::max<uint64_t>(1, (want_items + px / 2) / px), std::max<uint32_t>(max_chunks, 1u)));
         chunks = std::max<uint32_t>(1, std::min<uint32_t>(chunks, spp));
         P.chunk_spp = (spp + chunks - 1) / chunks;
     }
@@ -1962,12 +1967,11 @@ size_t partials_needed(const RenderParams& P) {
 
 // The body of rt_render_device.  work_counter / partials: the scene's own, or the caller's (the entry point that
 // allocates nothing brings its own).  d_dump: per-path colours of the kModeDump build, else null.
-int launch_render(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, float* d_sum_rgb, hipStream_t st,
-                  uint32_t* d_work_counter, float* d_partials, float* d_dump) {
+int launch_render(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, const RenderParams& P, float* d_sum_rgb,
+                  hipStream_t st, uint32_t* d_work_counter, float* d_partials, float* d_dump) {
     SceneDev S = scene->dev;
     S.eps = descent_eps(scene, camera_abs(*cam));
     const CamDev C = make_cam(*cam);
-    const RenderParams P = make_params(*cam, *opts);
     const uint64_t n_work = uint64_t(P.tiles_x) * P.tiles_y * 64u * P.n_chunks;
     // one render of a handle at a time on the device: they share the work counter and the partial sums
     RT_HIP(hipStreamWaitEvent(st, scene->ev_done, 0));
@@ -2025,7 +2029,52 @@ int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_render_opts
     RT_HIP(hipSetDevice(scene->device));
     // grown on first use unless rt_scene_reserve has sized it (the one case in which this call waits and allocates)
     if ((rc = reserve_partials(scene, partials_needed(make_params(*cam, *opts)))) != RT_OK) return rc;
-    return launch_render(scene, cam, opts, d_sum_rgb, static_cast<hipStream_t>(stream), scene->d_work_counter, scene->d_partials, nullptr);
+    return launch_render(scene, cam, opts, make_params(*cam, *opts), d_sum_rgb, static_cast<hipStream_t>(stream), scene->d_work_counter,
+                         scene->d_partials, nullptr);
+}
+
+namespace {
+// Device address of `scratch` on each device, asked once per device with that device current.
+constexpr int kMaxDevices = 64;
+unsigned char* g_scratch_ptr[kMaxDevices] = {};
+std::mutex g_scratch_mutex;
+
+int scratch_of_current_device(int device, unsigned char** out) {
+    if (device < 0 || device >= kMaxDevices) return fail(RT_ERR_LIMIT, "rt_render_device_noalloc: device %d beyond %d", device, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(rt::scratch));
+        if (e != hipSuccess || !p) return fail(RT_ERR_DEVICE, "rt_render_device_noalloc: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
+        g_scratch_ptr[device] = static_cast<unsigned char*>(p);
+    }
+    *out = g_scratch_ptr[device];
+    return RT_OK;
+}
+}  // namespace
+
+int rt_render_device_noalloc(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, float* d_sum_rgb, void* stream) {
+    int rc = check_render_args(scene, cam, opts, "rt_render_device_noalloc");
+    if (rc != RT_OK) return rc;
+    if (!d_sum_rgb) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_device_noalloc: null output buffer");
+    if (opts->flags & (RT_RENDER_STATS | RT_RENDER_TIMING))
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_device_noalloc: the diagnostic builds report through the scene's own counter");
+    DeviceGuard guard;
+    RT_HIP(hipSetDevice(scene->device));
+    unsigned char* base = nullptr;
+    if ((rc = scratch_of_current_device(scene->device, &base)) != RT_OK) return rc;
+    constexpr size_t kHeader = 256, kPartialBytes = size_t(RT_NOALLOC_SCRATCH_BYTES) - kHeader;
+    const size_t slot = size_t(cam->horiz_res) * cam->vert_res * 3 * sizeof(float);
+    RenderParams P = make_params(*cam, *opts);
+    if (partials_needed(P) > kPartialBytes) {
+        if (opts->samples_per_item)
+            return fail(RT_ERR_LIMIT, "rt_render_device_noalloc: %u chunks of a %u x %u frame need %zu bytes of partial sums, the fixed scratch holds %zu",
+                        P.n_chunks, cam->horiz_res, cam->vert_res, partials_needed(P), kPartialBytes);
+        // chunk size left to the library: as many chunks as the scratch holds (one chunk needs no partial sums at all)
+        P = make_params(*cam, *opts, uint32_t(std::max<size_t>(kPartialBytes / slot, 1)));
+    }
+    return launch_render(scene, cam, opts, P, d_sum_rgb, static_cast<hipStream_t>(stream), reinterpret_cast<uint32_t*>(base),
+                         reinterpret_cast<float*>(base + kHeader), nullptr);
 }
 
 int rt_debug_render_paths(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, float* rgb) {
@@ -2046,7 +2095,7 @@ int rt_debug_render_paths(rt_scene* scene, const rt_camera* cam, const rt_render
         return fail(RT_ERR_DEVICE, "rt_debug_render_paths: hipMalloc failed");
     }
     if (hipMemset(d_dump, 0, n_paths * 3 * sizeof(float)) != hipSuccess) rc = fail(RT_ERR_DEVICE, "rt_debug_render_paths: hipMemset failed");
-    if (rc == RT_OK) rc = launch_render(scene, cam, opts, d_sum, nullptr, scene->d_work_counter, scene->d_partials, d_dump);
+    if (rc == RT_OK) rc = launch_render(scene, cam, opts, make_params(*cam, *opts), d_sum, nullptr, scene->d_work_counter, scene->d_partials, d_dump);
     if (rc == RT_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(RT_ERR_DEVICE, "rt_debug_render_paths: kernel execution failed");
     if (rc == RT_OK && hipMemcpy(rgb, d_dump, n_paths * 3 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
         rc = fail(RT_ERR_DEVICE, "rt_debug_render_paths: download failed");
