@@ -64,7 +64,9 @@ static_assert(sizeof(Node32) == 32, "Node32 must be 32 bytes");
 struct SceneDev {
     const Node* nodes;
     const Node32* nodes32;  // the same tree, quantised (render_kernel_ws without the scene in LDS)
-    float qbase[3], qstep[3];
+    float qbase[3], qstep[3];  // grid of nodes32
+    float hbase[3], hstep[3];  // the f16 boxes of the LDS-resident tree are (plane - hbase) / hstep
+    float eps_rel;             // origin widening of the render kernels' descent, which works relative to qbase / hbase
     const double4* sph;     // the n_tree spheres of the BVH in leaf order, then the n_wide spheres kept out of it
     const DiscDev* discs;   // scene order
     const float4* mat;      // spheres in leaf order, then discs: albedo rgb + (fuzz | refractive index)
@@ -728,9 +730,15 @@ __device__ __forceinline__ bool sphere_candidate(const double4 s, int32_t k, int
     return better;
 }
 
-// QUANT: the boxes will come as grid indices q (Node32), plane = qbase + q * qstep: the grid is folded into the
-// per-ray factors, t = fma(q, qstep / d, (qbase - (o +- eps)) / d), the same count of roundings as with f32 planes.
-template <bool QUANT>
+// The render kernels' descent works in coordinates RELATIVE to a point of the scene (`base`), in units of `step`:
+// a stored bound q stands for the plane base + q * step, and the affine map is folded into the per-ray factors,
+// t = fma(q, step / d, ((base - o) -+ eps) / d), with base - o formed in f64 from the path's f64 origin.  So the f32
+// roundings scale with distances inside the scene, not with the scene's distance from the coordinate origin, and a
+// translated scene is descended exactly like the untranslated one.  GRID = true: q are the 16-bit grid indices of
+// Node32 (base = the grid's low corner); GRID = false: q are the f16 values of Node16 (base = centre of the tree's
+// box, step = a power of two that brings the half extent to about 1024, inside f16's normal range whatever the
+// scene's scale).
+template <bool GRID>
 __device__ __forceinline__ void trav_begin(const SceneDev& S, const Tables& Tb, const Path& p, Trav& T, uint32_t slot1_addr) {
     T.best.t = 0.0;
     T.best.k = -1;
@@ -749,21 +757,17 @@ __device__ __forceinline__ void trav_begin(const SceneDev& S, const Tables& Tb, 
         sphere_candidate(Tb.sph[k], k, Tb.prim_id[k], p, spheres_matter, T.best);
     }
     T.node = (S.n_nodes == 0 || !spheres_matter) ? kLeafSentinel : 0;
-    const float of[3] = {float(p.ox), float(p.oy), float(p.oz)};
+    const double o64[3] = {p.ox, p.oy, p.oz};
     const float df[3] = {float(p.dx), float(p.dy), float(p.dz)};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const float d = df[a];
         const float i = (fabsf(d) >= 1.0e-18f) ? fast_rcp(d) : copysignf(1.0e18f, d);
-        if (QUANT) {
-            T.inv[a] = S.qstep[a] * i;
-            T.A[a] = (S.qbase[a] - (of[a] + S.eps)) * i;
-            T.B[a] = (S.qbase[a] - (of[a] - S.eps)) * i;
-        } else {
-            T.inv[a] = i;
-            T.A[a] = -(of[a] + S.eps) * i;
-            T.B[a] = -(of[a] - S.eps) * i;
-        }
+        const float base = GRID ? S.qbase[a] : S.hbase[a], step = GRID ? S.qstep[a] : S.hstep[a];
+        const float rel = float(double(base) - o64[a]);  // base - origin, rounded once
+        T.inv[a] = step * i;
+        T.A[a] = (rel - S.eps_rel) * i;
+        T.B[a] = (rel + S.eps_rel) * i;
     }
     T.tmax = (T.best.k >= 0) ? float(T.best.t) * (1.0f + 4.0e-7f) : 3.0e38f;
 }
@@ -1452,6 +1456,7 @@ struct rt_scene {
     uint32_t stack_depth = 0;
     int n_cu = 0;
     double bound_abs = 0.0;  // largest |coordinate| of any box corner
+    double bound_rel = 0.0;  // largest distance, per axis, of any box corner from the reference points hbase / qbase
     hipEvent_t ev_done = nullptr;  // recorded after every render of this handle: the next render waits for it, on any stream
     // workgroups per CU of each render kernel variant for this scene's LDS footprint, 0 = not asked yet
     // ([0] lock-step kernel, [1 + mode] wave-scheduled kernel with the tree in HBM, [5 + mode] with the scene in LDS)
@@ -1463,9 +1468,9 @@ namespace {
 // IEEE half bits of the largest half <= x (down) or the smallest half >= x (up); overflow gives +-inf.
 uint16_t half_bits(_Float16 h) { uint16_t b; std::memcpy(&b, &h, 2); return b; }
 _Float16 half_from_bits(uint16_t b) { _Float16 h; std::memcpy(&h, &b, 2); return h; }
-uint16_t half_round_down(float x) {
+uint16_t half_round_down(double x) {
     _Float16 h = _Float16(x);
-    if (float(h) > x) {
+    if (double(h) > x) {
         uint16_t b = half_bits(h);
         if ((b & 0x7fffu) == 0) b = 0x8001u;          // below zero: smallest negative subnormal
         else if (b & 0x8000u) b = uint16_t(b + 1);    // negative: larger magnitude
@@ -1474,9 +1479,9 @@ uint16_t half_round_down(float x) {
     }
     return half_bits(h);
 }
-uint16_t half_round_up(float x) {
+uint16_t half_round_up(double x) {
     _Float16 h = _Float16(x);
-    if (float(h) < x) {
+    if (double(h) < x) {
         uint16_t b = half_bits(h);
         if ((b & 0x7fffu) == 0) b = 0x0001u;
         else if (b & 0x8000u) b = uint16_t(b - 1);    // negative (incl. -inf -> -65504)
@@ -1629,6 +1634,17 @@ RenderParams make_params(const rt_camera& cam, const rt_render_opts& o, uint32_t
     // tuning aid: issue priorities of the three phases, two bits each (inner loop | leaf turn << 2 | shade << 4)
     if (const char* e = std::getenv("RT_PHASE_PRIORITY")) P.flags |= (uint32_t(std::atoi(e)) & 63u) << 16;
     return P;
+}
+
+// eps of the render kernels, whose descent works relative to hbase / qbase: 2^-21 of the largest distance, on any
+// axis, between a box plane and a path origin (origins lie on surfaces or on the camera's lens)
+float descent_eps_rel(const rt_scene* sc, const rt_camera& c) {
+    double m = sc->bound_rel;
+    for (int a = 0; a < 3; ++a) {
+        m = std::max(m, std::fabs(c.lookfrom[a] - double(sc->dev.hbase[a])) + std::fabs(c.aperture));
+        m = std::max(m, std::fabs(c.lookfrom[a] - double(sc->dev.qbase[a])) + std::fabs(c.aperture));
+    }
+    return float(2.0 * m * (1.0 / 2097152.0));
 }
 
 double camera_abs(const rt_camera& c) {
@@ -1838,17 +1854,37 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
     }
 
     int rc;
-    // f16 copy of the nodes for the LDS-resident kernel: scenes that leave room for two workgroups per CU
+    // box around every finite node box (the f32 boxes are rounded outward, so it may exceed the spheres' box by an ulp)
+    double glo[3], ghi[3];
+    for (int a = 0; a < 3; ++a) { glo[a] = bvh.scene_lo[a]; ghi[a] = bvh.scene_hi[a]; }
+    for (const Node& nd : bvh.nodes)
+        for (int a = 0; a < 3; ++a) {
+            if (nd.lo0[a] < 3.0e38f) { glo[a] = std::min(glo[a], double(nd.lo0[a])); ghi[a] = std::max(ghi[a], double(nd.hi0[a])); }
+            if (nd.lo1[a] < 3.0e38f) { glo[a] = std::min(glo[a], double(nd.lo1[a])); ghi[a] = std::max(ghi[a], double(nd.hi1[a])); }
+        }
+    // f16 copy of the nodes for the LDS-resident kernel: scenes that leave room for two workgroups per CU.  The
+    // values are (plane - hbase) / hstep with hbase = the centre of the box above and hstep a power of two that puts
+    // the half extent in [512, 1024): f16 then resolves 2^-11 of a plane's distance from the scene's centre, whatever
+    // the scene's position and scale (taken as absolute coordinates, half floats have an ulp of 8 at 1e4 and end at 65504).
+    for (int a = 0; a < 3; ++a) {
+        const float centre = float(0.5 * (glo[a] + ghi[a]));
+        const double half = std::max(std::max(ghi[a] - double(centre), double(centre) - glo[a]), 1.0e-30);
+        int e = 0;
+        (void)std::frexp(half, &e);  // half = m * 2^e, m in [0.5, 1)
+        sc->dev.hbase[a] = centre;
+        sc->dev.hstep[a] = std::ldexp(1.0f, e - 10);  // half / hstep = m * 2^10 in [512, 1024)
+    }
     {
         const size_t n_prims = n_s + n_d;
         const size_t scene_bytes = 32 * bvh.nodes.size() + 32 * n_s + 16 * n_prims + 2 * 16 * ((n_prims + 3) / 4);
         if (n_s > 0 && lds16_launch_bytes(scene_bytes, sc->stack_depth) <= kLdsPerCu / 2) {
             std::vector<Node16> n16(bvh.nodes.size());
+            auto rel = [&](float plane, int a) { return (double(plane) - double(sc->dev.hbase[a])) / double(sc->dev.hstep[a]); };  // exact
             for (size_t i = 0; i < bvh.nodes.size(); ++i) {
                 const Node& nd = bvh.nodes[i];
                 for (int a = 0; a < 3; ++a) {
-                    n16[i].h[a] = half_round_down(nd.lo0[a]); n16[i].h[3 + a] = half_round_up(nd.hi0[a]);
-                    n16[i].h[6 + a] = half_round_down(nd.lo1[a]); n16[i].h[9 + a] = half_round_up(nd.hi1[a]);
+                    n16[i].h[a] = half_round_down(rel(nd.lo0[a], a)); n16[i].h[3 + a] = half_round_up(rel(nd.hi0[a], a));
+                    n16[i].h[6 + a] = half_round_down(rel(nd.lo1[a], a)); n16[i].h[9 + a] = half_round_up(rel(nd.hi1[a], a));
                 }
                 n16[i].child0 = nd.child0; n16[i].child1 = nd.child1;
             }
@@ -1859,13 +1895,6 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
     {
         // 16-bit grid over the box of the tree's spheres; base and step are f32 values first, the indices are then
         // chosen in f64 against exactly those values, so that base + q * step never cuts into a box
-        double glo[3], ghi[3];
-        for (int a = 0; a < 3; ++a) { glo[a] = bvh.scene_lo[a]; ghi[a] = bvh.scene_hi[a]; }
-        for (const Node& nd : bvh.nodes)
-            for (int a = 0; a < 3; ++a) {
-                if (nd.lo0[a] < 3.0e38f) { glo[a] = std::min(glo[a], double(nd.lo0[a])); ghi[a] = std::max(ghi[a], double(nd.hi0[a])); }
-                if (nd.lo1[a] < 3.0e38f) { glo[a] = std::min(glo[a], double(nd.lo1[a])); ghi[a] = std::max(ghi[a], double(nd.hi1[a])); }
-            }
         float base[3], step[3];
         for (int a = 0; a < 3; ++a) {
             base[a] = std::nextafter(float(glo[a]), -INFINITY);
@@ -1912,6 +1941,17 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
     sc->dev.n_wide = int32_t(n_wide);
     sc->dev.n_discs = int32_t(n_d);
     sc->dev.eps = 0.0f;
+    sc->dev.eps_rel = 0.0f;
+    {   // every surface's box against the two reference points of the relative descent
+        double rel = 0.0;
+        auto take = [&](const double c[3], double r) {
+            for (int a = 0; a < 3; ++a)
+                for (float base : {sc->dev.hbase[a], sc->dev.qbase[a]})
+                    rel = std::max(rel, std::fabs(c[a] - double(base)) + std::fabs(r));
+        };
+        for (const rt_hittable& h : sc->hittables) take(h.centre, h.radius);
+        sc->bound_rel = rel;
+    }
     {
         void* p = nullptr;
         if (hipMalloc(&p, 256) != hipSuccess) return bail(fail(RT_ERR_DEVICE, "rt_scene_create: hipMalloc of the work counter failed"));
@@ -1971,6 +2011,7 @@ int launch_render(rt_scene* scene, const rt_camera* cam, const rt_render_opts* o
                   hipStream_t st, uint32_t* d_work_counter, float* d_partials, float* d_dump) {
     SceneDev S = scene->dev;
     S.eps = descent_eps(scene, camera_abs(*cam));
+    S.eps_rel = descent_eps_rel(scene, *cam);
     const CamDev C = make_cam(*cam);
     const uint64_t n_work = uint64_t(P.tiles_x) * P.tiles_y * 64u * P.n_chunks;
     // one render of a handle at a time on the device: they share the work counter and the partial sums

@@ -767,3 +767,41 @@ def test_render_device_only_enqueues_once_reserved(rt, scene1):
     assert np.array_equal(ra, rb) and np.isfinite(ra).all()
     want, _ = scene1.render(cam, spp, depth=50, seed=0, want_rgb8=False)
     assert np.array_equal(ra.reshape(1080, 1920, 3), want)
+
+
+def test_translated_scene_is_descended_like_the_untranslated_one(rt, ob, scene1):
+    """The LDS-resident tree keeps its boxes as f16 values relative to the scene's centre and the descent works in
+    those relative coordinates, so a scene far from the coordinate origin (where a half float has an ulp of 8 or more)
+    is traversed with the same boxes, hence the same number of steps, as the scene at the origin."""
+    from raytracer_amd import _abi
+
+    shift = np.array([2.0e4, 0.0, 2.0e4])
+    h = rt.gen_scene(1)
+    moved_h = h.copy()
+    moved_h["centre"] += shift
+    moved, omoved = rt.Scene(moved_h), ob.Scene(moved_h)
+    assert moved.info["lds_resident"] == 1 and moved.info["n_wide"] == 1
+    cam = rt.default_camera(160, 96)
+    cam_moved = rt.Camera.build(list(shift), list(np.array([13, 1.5, 3]) + shift), 1.0, 0.1, 160, 96)
+    o, d = moved.generate_primary(cam_moved, seed=0, pixel_begin=0, pixel_end=160 * 96)
+    ids, t, nrm = moved.trace_primary(o, d)
+    want_ids, want_t, want_n, _ = omoved.trace(o, d, ob.TRAVERSE_GATED_BRUTE)
+    _check_hits(ids, t, nrm, want_ids, want_t, want_n)
+
+    def steps_per_path(scene, camera, spp=8):
+        s, _ = scene.render(camera, spp, depth=50, seed=0, flags=_abi.RT_RENDER_STATS, want_rgb8=False)
+        st = np.zeros(8, dtype=np.uint64)
+        _abi.check(_abi.lib.rt_debug_render_stats(scene.handle, st.ctypes.data))
+        return float(st[1]) / (160 * 96 * spp), s
+
+    here, img = steps_per_path(scene1, cam)
+    there, img_moved = steps_per_path(moved, cam_moved)
+    assert abs(there - here) < 0.1 * here, (here, there)
+    assert abs(img_moved.mean() - img.mean()) < 0.02 * img.mean()
+    # the render kernel's paths on the moved scene against the oracle (the f32 camera ray is coarse out there, the
+    # paths it starts are still the oracle's)
+    got = moved.render_paths(cam_moved, 2, depth=10, seed=4).reshape(-1, 3).astype(np.float64)
+    assert np.isfinite(got).all()
+    px = np.repeat(np.arange(160 * 96, dtype=np.uint32), 2)
+    sm = np.tile(np.arange(2, dtype=np.uint32), 160 * 96)
+    assert np.array_equal(got.astype(np.float32), moved.trace_paths(cam_moved, px, sm, depth=10, seed=4))
