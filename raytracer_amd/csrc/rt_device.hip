@@ -53,10 +53,13 @@ struct TexImgDev {
 };
 
 // Node of the HBM-resident tree as the render kernel reads it: the boxes of both children on a 16-bit grid over
-// the scene box (plane = qbase + q * qstep per axis; lower bounds rounded down, upper bounds up, so the boxes only
-// grow) + 2 child links: 32 bytes = two 16-byte loads per lane instead of the four of the f32 Node.
+// the scene box (coordinate = qbase + q * qstep per axis), each as CENTRE and HALF EXTENT per axis (the centre is a
+// grid point, the half extent is rounded up so that the box only grows) + 2 child links: 32 bytes = two 16-byte
+// loads per lane instead of the four of the f32 Node.  Centre / half extent instead of low / high bound: the slab
+// test then needs no min / max per axis (near and far parameter are centre -+ half extent times |1/d|), and the two
+// children's additions pair up in packed instructions.
 struct Node32 {
-    uint16_t q[12];  // lo0.xyz hi0.xyz lo1.xyz hi1.xyz
+    uint16_t q[12];  // per axis x, y, z: centre of child 0, centre of child 1, half extent of child 0, of child 1
     int32_t child0, child1;
 };
 static_assert(sizeof(Node32) == 32, "Node32 must be 32 bytes");
@@ -687,7 +690,7 @@ constexpr int kInnerThreshold = 8;
 constexpr int kLeaveThreshold = 20;  // lanes that may leave the inner nodes before the wave turns to the leaves
 
 struct Node16 {       // 32 bytes: two 16-byte LDS reads
-    uint16_t h[12];   // lo0.xyz hi0.xyz lo1.xyz hi1.xyz as IEEE half bits
+    uint16_t h[12];   // IEEE half bits; per axis x, y, z: centre of child 0, of child 1, half extent of child 0, of child 1
     int32_t child0, child1;
 };
 static_assert(sizeof(Node16) == 32, "Node16 must be 32 bytes");
@@ -695,7 +698,7 @@ static_assert(sizeof(Node16) == 32, "Node16 must be 32 bytes");
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
 struct Trav {
-    float inv[3], A[3], B[3];
+    float inv[3], A[3], E[3];  // per axis: step / d, (base - origin) / d, eps / |d|  (see trav_begin)
     float tmax;
     int32_t node;
     uint32_t sp;  // LDS byte address of the next free slot of this lane's stack column (slots are BLOCK * 4 bytes apart)
@@ -731,8 +734,10 @@ __device__ __forceinline__ bool sphere_candidate(const double4 s, int32_t k, int
 }
 
 // The render kernels' descent works in coordinates RELATIVE to a point of the scene (`base`), in units of `step`:
-// a stored bound q stands for the plane base + q * step, and the affine map is folded into the per-ray factors,
-// t = fma(q, step / d, ((base - o) -+ eps) / d), with base - o formed in f64 from the path's f64 origin.  So the f32
+// a stored value q stands for the coordinate base + q * step, and the affine map is folded into the per-ray factors:
+// a box with centre c and half extent h on an axis is crossed between t_c - w and t_c + w, where
+// t_c = fma(c, step / d, (base - o) / d) and w = fma(h, |step / d|, eps / |d|), with base - o formed in f64 from the
+// path's f64 origin.  So the f32
 // roundings scale with distances inside the scene, not with the scene's distance from the coordinate origin, and a
 // translated scene is descended exactly like the untranslated one.  GRID = true: q are the 16-bit grid indices of
 // Node32 (base = the grid's low corner); GRID = false: q are the f16 values of Node16 (base = centre of the tree's
@@ -766,25 +771,28 @@ __device__ __forceinline__ void trav_begin(const SceneDev& S, const Tables& Tb, 
         const float base = GRID ? S.qbase[a] : S.hbase[a], step = GRID ? S.qstep[a] : S.hstep[a];
         const float rel = float(double(base) - o64[a]);  // base - origin, rounded once
         T.inv[a] = step * i;
-        T.A[a] = (rel - S.eps_rel) * i;
-        T.B[a] = (rel + S.eps_rel) * i;
+        T.A[a] = rel * i;
+        T.E[a] = S.eps_rel * fabsf(i);
     }
     T.tmax = (T.best.k >= 0) ? float(T.best.t) * (1.0f + 4.0e-7f) : 3.0e38f;
 }
 
-__device__ __forceinline__ void slab2(const Trav& T, float lo0x, float lo0y, float lo0z, float hi0x, float hi0y,
-                                      float hi0z, float lo1x, float lo1y, float lo1z, float hi1x, float hi1y,
-                                      float hi1z, float* en0, float* ex0, float* en1, float* ex1) {
-    const float t0x = fmaf(lo0x, T.inv[0], T.A[0]), t1x = fmaf(hi0x, T.inv[0], T.B[0]);
-    const float t0y = fmaf(lo0y, T.inv[1], T.A[1]), t1y = fmaf(hi0y, T.inv[1], T.B[1]);
-    const float t0z = fmaf(lo0z, T.inv[2], T.A[2]), t1z = fmaf(hi0z, T.inv[2], T.B[2]);
-    *en0 = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
-    *ex0 = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), T.tmax));
-    const float u0x = fmaf(lo1x, T.inv[0], T.A[0]), u1x = fmaf(hi1x, T.inv[0], T.B[0]);
-    const float u0y = fmaf(lo1y, T.inv[1], T.A[1]), u1y = fmaf(hi1y, T.inv[1], T.B[1]);
-    const float u0z = fmaf(lo1z, T.inv[2], T.A[2]), u1z = fmaf(hi1z, T.inv[2], T.B[2]);
-    *en1 = fmaxf(fmaxf(fminf(u0x, u1x), fminf(u0y, u1y)), fmaxf(fminf(u0z, u1z), 0.0f));
-    *ex1 = fminf(fminf(fmaxf(u0x, u1x), fmaxf(u0y, u1y)), fminf(fmaxf(u0z, u1z), T.tmax));
+// Entry and exit parameters of the two child boxes of a node, from their centres c and half extents h (node units).
+__device__ __forceinline__ void slab2(const Trav& T, const float c0[3], const float c1[3], const float h0[3], const float h1[3],
+                                      float* en0, float* ex0, float* en1, float* ex1) {
+    float n0[3], f0[3], n1[3], f1[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float ai = fabsf(T.inv[a]);
+        const float tc0 = fmaf(c0[a], T.inv[a], T.A[a]), w0 = fmaf(h0[a], ai, T.E[a]);
+        const float tc1 = fmaf(c1[a], T.inv[a], T.A[a]), w1 = fmaf(h1[a], ai, T.E[a]);
+        n0[a] = tc0 - w0; f0[a] = tc0 + w0;
+        n1[a] = tc1 - w1; f1[a] = tc1 + w1;
+    }
+    *en0 = fmaxf(fmaxf(n0[0], n0[1]), fmaxf(n0[2], 0.0f));
+    *ex0 = fminf(fminf(f0[0], f0[1]), fminf(f0[2], T.tmax));
+    *en1 = fmaxf(fmaxf(n1[0], n1[1]), fmaxf(n1[2], 0.0f));
+    *ex1 = fminf(fminf(f1[0], f1[1]), fminf(f1[2], T.tmax));
 }
 
 // The stack keeps its top in T.top and the rest in LDS (this lane's column: slot `level` at column base +
@@ -818,26 +826,24 @@ template <bool LDS16, int BLOCK>
 __device__ __forceinline__ void inner_step(const SceneDev& S, const uint4* lds_q0, const uint4* lds_q1, Trav& T) {
     float en0, ex0, en1, ex1;
     int32_t c0, c1;
-    if (LDS16) {
-        const uint4 a = lds_q0[T.node], b = lds_q1[T.node];
-        const half2_t h0 = __builtin_bit_cast(half2_t, a.x), h1 = __builtin_bit_cast(half2_t, a.y);
-        const half2_t h2 = __builtin_bit_cast(half2_t, a.z), h3 = __builtin_bit_cast(half2_t, a.w);
-        const half2_t h4 = __builtin_bit_cast(half2_t, b.x), h5 = __builtin_bit_cast(half2_t, b.y);
-        // h0 = lo0.xy  h1 = lo0.z hi0.x  h2 = hi0.yz  h3 = lo1.xy  h4 = lo1.z hi1.x  h5 = hi1.yz
-        slab2(T, float(h0.x), float(h0.y), float(h1.x), float(h1.y), float(h2.x), float(h2.y), float(h3.x), float(h3.y),
-              float(h4.x), float(h4.y), float(h5.x), float(h5.y), &en0, &ex0, &en1, &ex1);
-        c0 = int32_t(b.z);
-        c1 = int32_t(b.w);
-    } else {
-        const uint4* q = reinterpret_cast<const uint4*>(S.nodes32 + T.node);
-        const uint4 a = q[0], b = q[1];
-        // a.x = lo0.x lo0.y  a.y = lo0.z hi0.x  a.z = hi0.y hi0.z  a.w = lo1.x lo1.y  b.x = lo1.z hi1.x  b.y = hi1.y hi1.z
-        slab2(T, float(a.x & 0xffffu), float(a.x >> 16), float(a.y & 0xffffu), float(a.y >> 16), float(a.z & 0xffffu),
-              float(a.z >> 16), float(a.w & 0xffffu), float(a.w >> 16), float(b.x & 0xffffu), float(b.x >> 16),
-              float(b.y & 0xffffu), float(b.y >> 16), &en0, &ex0, &en1, &ex1);
-        c0 = int32_t(b.z);
-        c1 = int32_t(b.w);
+    // dwords: a.x = centres x (child 0 | child 1 << 16), a.y = half extents x, a.z / a.w = the same for y, b.x / b.y for z
+    uint4 a, b;
+    if (LDS16) { a = lds_q0[T.node]; b = lds_q1[T.node]; }
+    else { const uint4* q = reinterpret_cast<const uint4*>(S.nodes32 + T.node); a = q[0]; b = q[1]; }
+    const uint32_t cw[3] = {a.x, a.z, b.x}, hw[3] = {a.y, a.w, b.y};
+    float ce0[3], ce1[3], he0[3], he1[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (LDS16) {
+            const half2_t c = __builtin_bit_cast(half2_t, cw[k]), h = __builtin_bit_cast(half2_t, hw[k]);
+            ce0[k] = float(c.x); ce1[k] = float(c.y); he0[k] = float(h.x); he1[k] = float(h.y);
+        } else {
+            ce0[k] = float(cw[k] & 0xffffu); ce1[k] = float(cw[k] >> 16); he0[k] = float(hw[k] & 0xffffu); he1[k] = float(hw[k] >> 16);
+        }
     }
+    slab2(T, ce0, ce1, he0, he1, &en0, &ex0, &en1, &ex1);
+    c0 = int32_t(b.z);
+    c1 = int32_t(b.w);
     descend<BLOCK>(T, en0, ex0, en1, ex1, c0, c1);
 }
 
@@ -886,51 +892,47 @@ __device__ __forceinline__ void inner_loop_lds16(Trav& T, uint32_t q0_addr, uint
         "ds_read_b128 v[124:127], v113\n\t"
         "1:\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
-        // child 0: v120 = lo.x lo.y | v121 = lo.z hi.x | v122 = hi.y hi.z
+        // x: v120 = centres (child 0 | child 1), v121 = half extents
         "v_fma_mix_f32 v112, v120, %[ix], %[ax] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 v113, v121, %[ix], %[bx] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 v114, v120, %[iy], %[ay] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 v115, v122, %[iy], %[by] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 v116, v121, %[iz], %[az] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 v117, v122, %[iz], %[bz] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_min_f32_e32 v118, v112, v113\n\t"
-        "v_max_f32_e32 v112, v112, v113\n\t"
-        "v_min_f32_e32 v113, v114, v115\n\t"
-        "v_max_f32_e32 v114, v114, v115\n\t"
-        "v_min_f32_e32 v115, v116, v117\n\t"
-        "v_max_f32_e32 v116, v116, v117\n\t"
-        "v_max_f32_e32 v115, 0, v115\n\t"
-        "v_min_f32_e32 v116, v116, %[tmax]\n\t"
-        "v_max3_f32 v118, v118, v113, v115\n\t"   // entry parameter of child 0
-        "v_min3_f32 v119, v112, v114, v116\n\t"   // exit parameter of child 0
-        // child 1: v123 = lo.x lo.y | v124 = lo.z hi.x | v125 = hi.y hi.z
-        "v_fma_mix_f32 v112, v123, %[ix], %[ax] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 v113, v124, %[ix], %[bx] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 v114, v123, %[iy], %[ay] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 v115, v125, %[iy], %[by] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 v116, v124, %[iz], %[az] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 v117, v125, %[iz], %[bz] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_min_f32_e32 v122, v112, v113\n\t"
-        "v_max_f32_e32 v112, v112, v113\n\t"
-        "v_min_f32_e32 v113, v114, v115\n\t"
-        "v_max_f32_e32 v114, v114, v115\n\t"
-        "v_min_f32_e32 v115, v116, v117\n\t"
-        "v_max_f32_e32 v116, v116, v117\n\t"
-        "v_max_f32_e32 v115, 0, v115\n\t"
-        "v_min_f32_e32 v116, v116, %[tmax]\n\t"
-        "v_max3_f32 v122, v122, v113, v115\n\t"   // entry parameter of child 1
-        "v_min3_f32 v120, v112, v114, v116\n\t"   // exit parameter of child 1
+        "v_fma_mix_f32 v113, v120, %[ix], %[ax] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 v114, v121, |%[ix]|, %[ex] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 v115, v121, |%[ix]|, %[ex] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_pk_add_f32 v[116:117], v[112:113], v[114:115] neg_lo:[0,1] neg_hi:[0,1]\n\t"   // near parameters
+        "v_pk_add_f32 v[112:113], v[112:113], v[114:115]\n\t"   // far parameters
+        // y: v122 = centres (child 0 | child 1), v123 = half extents
+        "v_fma_mix_f32 v114, v122, %[iy], %[ay] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 v115, v122, %[iy], %[ay] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 v120, v123, |%[iy]|, %[ey] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 v121, v123, |%[iy]|, %[ey] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_pk_add_f32 v[118:119], v[114:115], v[120:121] neg_lo:[0,1] neg_hi:[0,1]\n\t"   // near parameters
+        "v_pk_add_f32 v[114:115], v[114:115], v[120:121]\n\t"   // far parameters
+        // z: v124 = centres (child 0 | child 1), v125 = half extents
+        "v_fma_mix_f32 v120, v124, %[iz], %[az] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 v121, v124, %[iz], %[az] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 v122, v125, |%[iz]|, %[ez] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 v123, v125, |%[iz]|, %[ez] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_pk_add_f32 v[124:125], v[120:121], v[122:123]\n\t"   // far parameters
+        "v_pk_add_f32 v[122:123], v[120:121], v[122:123] neg_lo:[0,1] neg_hi:[0,1]\n\t"   // near parameters
+        // near x / y / z = v116,117 / v118,119 / v122,123; far = v112,113 / v114,115 / v124,125 (child 0, child 1)
+        "v_max_f32_e32 v122, 0, v122\n\t"
+        "v_max_f32_e32 v123, 0, v123\n\t"
+        "v_min_f32_e32 v124, v124, %[tmax]\n\t"
+        "v_min_f32_e32 v125, v125, %[tmax]\n\t"
+        "v_max3_f32 v116, v116, v118, v122\n\t"   // entry parameter of child 0
+        "v_min3_f32 v112, v112, v114, v124\n\t"   // exit parameter of child 0
+        "v_max3_f32 v117, v117, v119, v123\n\t"   // entry parameter of child 1
+        "v_min3_f32 v113, v113, v115, v125\n\t"   // exit parameter of child 1
         // v126, v127 = child links c0, c1
-        "v_cmp_le_f32_e64 s[90:91], v118, v119\n\t"   // h0
-        "v_cmp_le_f32_e64 s[92:93], v122, v120\n\t"   // h1
-        "v_cmp_lt_f32_e64 s[94:95], v122, v118\n\t"   // child 1 is entered first
+        "v_cmp_le_f32_e64 s[90:91], v116, v112\n\t"   // h0
+        "v_cmp_le_f32_e64 s[92:93], v117, v113\n\t"   // h1
+        "v_cmp_lt_f32_e64 s[94:95], v117, v116\n\t"   // child 1 is entered first
         "s_and_b64 s[96:97], s[90:91], s[92:93]\n\t"  // both
         "s_or_b64 s[98:99], s[90:91], s[92:93]\n\t"   // any
         "s_and_b64 s[94:95], s[94:95], s[92:93]\n\t"
         "s_andn2_b64 s[94:95], s[90:91], s[94:95]\n\t"  // go to c0: h0 and not (h1 and child 1 first)
         "s_andn2_b64 s[98:99], exec, s[98:99]\n\t"      // none
         "v_cndmask_b32_e64 %[node], v127, v126, s[94:95]\n\t"
-        "v_cndmask_b32_e64 v112, v126, v127, s[94:95]\n\t"  // the other child, pushed where both are hit
+        "v_cndmask_b32_e64 v118, v126, v127, s[94:95]\n\t"  // the other child, pushed where both are hit
         "v_cndmask_b32_e64 %[node], %[node], %[top], s[98:99]\n\t"  // no child hit: go on with the stack top
         // every lane's next node is known: decide whether the loop goes on, and if so start the next fetch before
         // the stack is brought up to date
@@ -940,14 +942,14 @@ __device__ __forceinline__ void inner_loop_lds16(Trav& T, uint32_t q0_addr, uint
         "s_cbranch_scc0 5f\n\t"
         "6:\n\t"
         "s_mov_b64 exec, vcc\n\t"
-        "v_lshl_add_u32 v113, %[node], 4, %[q0]\n\t"
-        "v_lshl_add_u32 v114, %[node], 4, %[q1]\n\t"
-        "ds_read_b128 v[120:123], v113\n\t"
-        "ds_read_b128 v[124:127], v114\n\t"
+        "v_lshl_add_u32 v112, %[node], 4, %[q0]\n\t"
+        "v_lshl_add_u32 v113, %[node], 4, %[q1]\n\t"
+        "ds_read_b128 v[120:123], v112\n\t"
+        "ds_read_b128 v[124:127], v113\n\t"
         "s_mov_b64 exec, s[96:97]\n\t"               // push
         "ds_write_b32 %[sp], %[top]\n\t"
         "v_add_u32_e32 %[sp], %[stride], %[sp]\n\t"
-        "v_mov_b32_e32 %[top], v112\n\t"
+        "v_mov_b32_e32 %[top], v118\n\t"
         "s_mov_b64 exec, s[98:99]\n\t"               // pop
         "v_subrev_u32_e32 %[sp], %[stride], %[sp]\n\t"
         "ds_read_b32 %[top], %[sp]\n\t"
@@ -964,7 +966,7 @@ __device__ __forceinline__ void inner_loop_lds16(Trav& T, uint32_t q0_addr, uint
         "s_mov_b64 exec, s[96:97]\n\t"               // push
         "ds_write_b32 %[sp], %[top]\n\t"
         "v_add_u32_e32 %[sp], %[stride], %[sp]\n\t"
-        "v_mov_b32_e32 %[top], v112\n\t"
+        "v_mov_b32_e32 %[top], v118\n\t"
         "s_mov_b64 exec, s[98:99]\n\t"               // pop
         "v_subrev_u32_e32 %[sp], %[stride], %[sp]\n\t"
         "ds_read_b32 %[top], %[sp]\n\t"
@@ -973,7 +975,7 @@ __device__ __forceinline__ void inner_loop_lds16(Trav& T, uint32_t q0_addr, uint
         "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
         : [node] "+v"(T.node), [sp] "+v"(T.sp), [top] "+v"(T.top), [cnt] "=&s"(lanes_on_inner)
         : [ix] "v"(T.inv[0]), [iy] "v"(T.inv[1]), [iz] "v"(T.inv[2]), [ax] "v"(T.A[0]), [ay] "v"(T.A[1]),
-          [az] "v"(T.A[2]), [bx] "v"(T.B[0]), [by] "v"(T.B[1]), [bz] "v"(T.B[2]), [tmax] "v"(T.tmax),
+          [az] "v"(T.A[2]), [ex] "v"(T.E[0]), [ey] "v"(T.E[1]), [ez] "v"(T.E[2]), [tmax] "v"(T.tmax),
           [q0] "s"(q0_addr), [q1] "s"(q1_addr), [thr] "s"(thr), [sentinel] "s"(kLeafSentinel),
           [stride] "s"(uint32_t(BLOCK * sizeof(int32_t)))
         : "memory", "vcc", "scc", "v112", "v113", "v114", "v115", "v116", "v117",
@@ -1012,63 +1014,59 @@ __device__ __forceinline__ void inner_loop_hbm(Trav& T, const Node32* nodes32, i
         "global_load_dwordx4 v[124:127], v112, %[base] offset:16\n\t"
         "1:\n\t"
         "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
-        // child 0: v120 = lo.x lo.y | v121 = lo.z hi.x | v122 = hi.y hi.z as 16-bit grid indices
+        // x: v120 = centres (child 0 | child 1), v121 = half extents
         "v_cvt_f32_u32_sdwa v112, v120 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
-        "v_cvt_f32_u32_sdwa v113, v121 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-        "v_cvt_f32_u32_sdwa v114, v120 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-        "v_cvt_f32_u32_sdwa v115, v122 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
-        "v_cvt_f32_u32_sdwa v116, v121 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
-        "v_cvt_f32_u32_sdwa v117, v122 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+        "v_cvt_f32_u32_sdwa v113, v120 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+        "v_cvt_f32_u32_sdwa v114, v121 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
+        "v_cvt_f32_u32_sdwa v115, v121 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
         "v_fma_f32 v112, v112, %[ix], %[ax]\n\t"
-        "v_fma_f32 v113, v113, %[ix], %[bx]\n\t"
+        "v_fma_f32 v113, v113, %[ix], %[ax]\n\t"
+        "v_fma_f32 v114, v114, |%[ix]|, %[ex]\n\t"
+        "v_fma_f32 v115, v115, |%[ix]|, %[ex]\n\t"
+        "v_pk_add_f32 v[116:117], v[112:113], v[114:115] neg_lo:[0,1] neg_hi:[0,1]\n\t"   // near parameters
+        "v_pk_add_f32 v[112:113], v[112:113], v[114:115]\n\t"   // far parameters
+        // y: v122 = centres (child 0 | child 1), v123 = half extents
+        "v_cvt_f32_u32_sdwa v114, v122 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
+        "v_cvt_f32_u32_sdwa v115, v122 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+        "v_cvt_f32_u32_sdwa v120, v123 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
+        "v_cvt_f32_u32_sdwa v121, v123 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
         "v_fma_f32 v114, v114, %[iy], %[ay]\n\t"
-        "v_fma_f32 v115, v115, %[iy], %[by]\n\t"
-        "v_fma_f32 v116, v116, %[iz], %[az]\n\t"
-        "v_fma_f32 v117, v117, %[iz], %[bz]\n\t"
-        "v_min_f32_e32 v118, v112, v113\n\t"
-        "v_max_f32_e32 v112, v112, v113\n\t"
-        "v_min_f32_e32 v113, v114, v115\n\t"
-        "v_max_f32_e32 v114, v114, v115\n\t"
-        "v_min_f32_e32 v115, v116, v117\n\t"
-        "v_max_f32_e32 v116, v116, v117\n\t"
-        "v_max_f32_e32 v115, 0, v115\n\t"
-        "v_min_f32_e32 v116, v116, %[tmax]\n\t"
-        "v_max3_f32 v118, v118, v113, v115\n\t"   // entry parameter of child 0
-        "v_min3_f32 v119, v112, v114, v116\n\t"   // exit parameter of child 0
-        // child 1: v123 = lo.x lo.y | v124 = lo.z hi.x | v125 = hi.y hi.z
-        "v_cvt_f32_u32_sdwa v112, v123 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
-        "v_cvt_f32_u32_sdwa v113, v124 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-        "v_cvt_f32_u32_sdwa v114, v123 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-        "v_cvt_f32_u32_sdwa v115, v125 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
-        "v_cvt_f32_u32_sdwa v116, v124 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
-        "v_cvt_f32_u32_sdwa v117, v125 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-        "v_fma_f32 v112, v112, %[ix], %[ax]\n\t"
-        "v_fma_f32 v113, v113, %[ix], %[bx]\n\t"
-        "v_fma_f32 v114, v114, %[iy], %[ay]\n\t"
-        "v_fma_f32 v115, v115, %[iy], %[by]\n\t"
-        "v_fma_f32 v116, v116, %[iz], %[az]\n\t"
-        "v_fma_f32 v117, v117, %[iz], %[bz]\n\t"
-        "v_min_f32_e32 v122, v112, v113\n\t"
-        "v_max_f32_e32 v112, v112, v113\n\t"
-        "v_min_f32_e32 v113, v114, v115\n\t"
-        "v_max_f32_e32 v114, v114, v115\n\t"
-        "v_min_f32_e32 v115, v116, v117\n\t"
-        "v_max_f32_e32 v116, v116, v117\n\t"
-        "v_max_f32_e32 v115, 0, v115\n\t"
-        "v_min_f32_e32 v116, v116, %[tmax]\n\t"
-        "v_max3_f32 v122, v122, v113, v115\n\t"   // entry parameter of child 1
-        "v_min3_f32 v120, v112, v114, v116\n\t"   // exit parameter of child 1
+        "v_fma_f32 v115, v115, %[iy], %[ay]\n\t"
+        "v_fma_f32 v120, v120, |%[iy]|, %[ey]\n\t"
+        "v_fma_f32 v121, v121, |%[iy]|, %[ey]\n\t"
+        "v_pk_add_f32 v[118:119], v[114:115], v[120:121] neg_lo:[0,1] neg_hi:[0,1]\n\t"   // near parameters
+        "v_pk_add_f32 v[114:115], v[114:115], v[120:121]\n\t"   // far parameters
+        // z: v124 = centres (child 0 | child 1), v125 = half extents
+        "v_cvt_f32_u32_sdwa v120, v124 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
+        "v_cvt_f32_u32_sdwa v121, v124 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+        "v_cvt_f32_u32_sdwa v122, v125 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
+        "v_cvt_f32_u32_sdwa v123, v125 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+        "v_fma_f32 v120, v120, %[iz], %[az]\n\t"
+        "v_fma_f32 v121, v121, %[iz], %[az]\n\t"
+        "v_fma_f32 v122, v122, |%[iz]|, %[ez]\n\t"
+        "v_fma_f32 v123, v123, |%[iz]|, %[ez]\n\t"
+        "v_pk_add_f32 v[124:125], v[120:121], v[122:123]\n\t"   // far parameters
+        "v_pk_add_f32 v[122:123], v[120:121], v[122:123] neg_lo:[0,1] neg_hi:[0,1]\n\t"   // near parameters
+        // near x / y / z = v116,117 / v118,119 / v122,123; far = v112,113 / v114,115 / v124,125 (child 0, child 1)
+        "v_max_f32_e32 v122, 0, v122\n\t"
+        "v_max_f32_e32 v123, 0, v123\n\t"
+        "v_min_f32_e32 v124, v124, %[tmax]\n\t"
+        "v_min_f32_e32 v125, v125, %[tmax]\n\t"
+        "v_max3_f32 v116, v116, v118, v122\n\t"   // entry parameter of child 0
+        "v_min3_f32 v112, v112, v114, v124\n\t"   // exit parameter of child 0
+        "v_max3_f32 v117, v117, v119, v123\n\t"   // entry parameter of child 1
+        "v_min3_f32 v113, v113, v115, v125\n\t"   // exit parameter of child 1
         // v126, v127 = child links c0, c1
-        "v_cmp_le_f32_e64 s[90:91], v118, v119\n\t"   // h0
-        "v_cmp_le_f32_e64 s[92:93], v122, v120\n\t"   // h1
-        "v_cmp_lt_f32_e64 s[94:95], v122, v118\n\t"   // child 1 is entered first
+        "v_cmp_le_f32_e64 s[90:91], v116, v112\n\t"   // h0
+        "v_cmp_le_f32_e64 s[92:93], v117, v113\n\t"   // h1
+        "v_cmp_lt_f32_e64 s[94:95], v117, v116\n\t"   // child 1 is entered first
         "s_and_b64 s[96:97], s[90:91], s[92:93]\n\t"  // both
         "s_or_b64 s[98:99], s[90:91], s[92:93]\n\t"   // any
         "s_and_b64 s[94:95], s[94:95], s[92:93]\n\t"
         "s_andn2_b64 s[94:95], s[90:91], s[94:95]\n\t"  // go to c0: h0 and not (h1 and child 1 first)
         "s_andn2_b64 s[98:99], exec, s[98:99]\n\t"      // none
         "v_cndmask_b32_e64 %[node], v127, v126, s[94:95]\n\t"
-        "v_cndmask_b32_e64 v112, v126, v127, s[94:95]\n\t"  // the other child, pushed where both are hit
+        "v_cndmask_b32_e64 v118, v126, v127, s[94:95]\n\t"  // the other child, pushed where both are hit
         "v_cndmask_b32_e64 %[node], %[node], %[top], s[98:99]\n\t"  // no child hit: go on with the stack top
         // every lane's next node is known: decide whether the loop goes on, and if so start the next fetch before
         // the stack is brought up to date
@@ -1078,13 +1076,13 @@ __device__ __forceinline__ void inner_loop_hbm(Trav& T, const Node32* nodes32, i
         "s_cbranch_scc0 5f\n\t"
         "6:\n\t"
         "s_mov_b64 exec, vcc\n\t"
-        "v_lshlrev_b32_e32 v113, 5, %[node]\n\t"
-        "global_load_dwordx4 v[120:123], v113, %[base]\n\t"
-        "global_load_dwordx4 v[124:127], v113, %[base] offset:16\n\t"
+        "v_lshlrev_b32_e32 v112, 5, %[node]\n\t"
+        "global_load_dwordx4 v[120:123], v112, %[base]\n\t"
+        "global_load_dwordx4 v[124:127], v112, %[base] offset:16\n\t"
         "s_mov_b64 exec, s[96:97]\n\t"               // push
         "ds_write_b32 %[sp], %[top]\n\t"
         "v_add_u32_e32 %[sp], %[stride], %[sp]\n\t"
-        "v_mov_b32_e32 %[top], v112\n\t"
+        "v_mov_b32_e32 %[top], v118\n\t"
         "s_mov_b64 exec, s[98:99]\n\t"               // pop
         "v_subrev_u32_e32 %[sp], %[stride], %[sp]\n\t"
         "ds_read_b32 %[top], %[sp]\n\t"
@@ -1101,7 +1099,7 @@ __device__ __forceinline__ void inner_loop_hbm(Trav& T, const Node32* nodes32, i
         "s_mov_b64 exec, s[96:97]\n\t"               // push
         "ds_write_b32 %[sp], %[top]\n\t"
         "v_add_u32_e32 %[sp], %[stride], %[sp]\n\t"
-        "v_mov_b32_e32 %[top], v112\n\t"
+        "v_mov_b32_e32 %[top], v118\n\t"
         "s_mov_b64 exec, s[98:99]\n\t"               // pop
         "v_subrev_u32_e32 %[sp], %[stride], %[sp]\n\t"
         "ds_read_b32 %[top], %[sp]\n\t"
@@ -1110,7 +1108,7 @@ __device__ __forceinline__ void inner_loop_hbm(Trav& T, const Node32* nodes32, i
         "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
         : [node] "+v"(T.node), [sp] "+v"(T.sp), [top] "+v"(T.top), [cnt] "=&s"(lanes_on_inner)
         : [ix] "v"(T.inv[0]), [iy] "v"(T.inv[1]), [iz] "v"(T.inv[2]), [ax] "v"(T.A[0]), [ay] "v"(T.A[1]),
-          [az] "v"(T.A[2]), [bx] "v"(T.B[0]), [by] "v"(T.B[1]), [bz] "v"(T.B[2]), [tmax] "v"(T.tmax),
+          [az] "v"(T.A[2]), [ex] "v"(T.E[0]), [ey] "v"(T.E[1]), [ez] "v"(T.E[2]), [tmax] "v"(T.tmax),
           [base] "s"(base), [thr] "s"(thr), [sentinel] "s"(kLeafSentinel),
           [stride] "s"(uint32_t(BLOCK * sizeof(int32_t)))
         : "memory", "vcc", "scc", "v112", "v113", "v114", "v115", "v116", "v117",
@@ -1200,7 +1198,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     T.tmax = 0.0f;
     T.best.t = 0.0; T.best.k = -1; T.best.id = 0;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { T.inv[a] = 0.0f; T.A[a] = 0.0f; T.B[a] = 0.0f; }
+    for (int a = 0; a < 3; ++a) { T.inv[a] = 0.0f; T.A[a] = 0.0f; T.E[a] = 0.0f; }
     bool have_pixel = false, alive = false, done = false;
     uint32_t next_sample = 0, item_end = 0, chunk = 0, pix_xy = 0;
     float ar = 0.0f, ag = 0.0f, ab = 0.0f;
@@ -1465,20 +1463,9 @@ struct rt_scene {
 
 namespace {
 
-// IEEE half bits of the largest half <= x (down) or the smallest half >= x (up); overflow gives +-inf.
+// IEEE half bits of the smallest half >= x; overflow gives +inf.
 uint16_t half_bits(_Float16 h) { uint16_t b; std::memcpy(&b, &h, 2); return b; }
 _Float16 half_from_bits(uint16_t b) { _Float16 h; std::memcpy(&h, &b, 2); return h; }
-uint16_t half_round_down(double x) {
-    _Float16 h = _Float16(x);
-    if (double(h) > x) {
-        uint16_t b = half_bits(h);
-        if ((b & 0x7fffu) == 0) b = 0x8001u;          // below zero: smallest negative subnormal
-        else if (b & 0x8000u) b = uint16_t(b + 1);    // negative: larger magnitude
-        else b = uint16_t(b - 1);                     // positive (incl. +inf -> 65504)
-        h = half_from_bits(b);
-    }
-    return half_bits(h);
-}
 uint16_t half_round_up(double x) {
     _Float16 h = _Float16(x);
     if (double(h) < x) {
@@ -1636,7 +1623,7 @@ RenderParams make_params(const rt_camera& cam, const rt_render_opts& o, uint32_t
     return P;
 }
 
-// eps of the render kernels, whose descent works relative to hbase / qbase: 2^-21 of the largest distance, on any
+// eps of the render kernels, whose descent works relative to hbase / qbase: 2^-20 of the largest distance, on any
 // axis, between a box plane and a path origin (origins lie on surfaces or on the camera's lens)
 float descent_eps_rel(const rt_scene* sc, const rt_camera& c) {
     double m = sc->bound_rel;
@@ -1644,7 +1631,7 @@ float descent_eps_rel(const rt_scene* sc, const rt_camera& c) {
         m = std::max(m, std::fabs(c.lookfrom[a] - double(sc->dev.hbase[a])) + std::fabs(c.aperture));
         m = std::max(m, std::fabs(c.lookfrom[a] - double(sc->dev.qbase[a])) + std::fabs(c.aperture));
     }
-    return float(2.0 * m * (1.0 / 2097152.0));
+    return float(2.0 * m * (1.0 / 1048576.0));  // 2^-20: the centre / half-extent form takes two more roundings per axis
 }
 
 double camera_abs(const rt_camera& c) {
@@ -1880,11 +1867,20 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
         if (n_s > 0 && lds16_launch_bytes(scene_bytes, sc->stack_depth) <= kLdsPerCu / 2) {
             std::vector<Node16> n16(bvh.nodes.size());
             auto rel = [&](float plane, int a) { return (double(plane) - double(sc->dev.hbase[a])) / double(sc->dev.hstep[a]); };  // exact
+            // centre = the half float nearest to the box's middle, half extent = the smallest half float that still
+            // reaches both faces from that centre
+            auto encode = [&](float lo, float hi, int a, uint16_t* c_out, uint16_t* h_out) {
+                if (!(lo < 3.0e38f)) { *c_out = half_bits(_Float16(65504.0f)); *h_out = 0; return; }  // far-away point box
+                const double l = rel(lo, a), u = rel(hi, a);
+                const _Float16 c = _Float16(0.5 * (l + u));
+                *c_out = half_bits(c);
+                *h_out = half_round_up(std::max(u - double(c), double(c) - l));
+            };
             for (size_t i = 0; i < bvh.nodes.size(); ++i) {
                 const Node& nd = bvh.nodes[i];
                 for (int a = 0; a < 3; ++a) {
-                    n16[i].h[a] = half_round_down(rel(nd.lo0[a], a)); n16[i].h[3 + a] = half_round_up(rel(nd.hi0[a], a));
-                    n16[i].h[6 + a] = half_round_down(rel(nd.lo1[a], a)); n16[i].h[9 + a] = half_round_up(rel(nd.hi1[a], a));
+                    encode(nd.lo0[a], nd.hi0[a], a, &n16[i].h[4 * a], &n16[i].h[4 * a + 2]);
+                    encode(nd.lo1[a], nd.hi1[a], a, &n16[i].h[4 * a + 1], &n16[i].h[4 * a + 3]);
                 }
                 n16[i].child0 = nd.child0; n16[i].child1 = nd.child1;
             }
@@ -1920,8 +1916,12 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
         for (size_t i = 0; i < bvh.nodes.size(); ++i) {
             const Node& nd = bvh.nodes[i];
             for (int a = 0; a < 3; ++a) {
-                n32[i].q[a] = q_down(nd.lo0[a], a); n32[i].q[3 + a] = q_up(nd.hi0[a], a);
-                n32[i].q[6 + a] = q_down(nd.lo1[a], a); n32[i].q[9 + a] = q_up(nd.hi1[a], a);
+                // grid bounds (rounded outward), then centre and half extent in grid units: the centre is a grid
+                // point, the half extent reaches the farther bound
+                const uint32_t l0 = q_down(nd.lo0[a], a), u0 = q_up(nd.hi0[a], a), l1 = q_down(nd.lo1[a], a), u1 = q_up(nd.hi1[a], a);
+                const uint32_t c0 = (l0 + u0) / 2, c1 = (l1 + u1) / 2;
+                n32[i].q[4 * a] = uint16_t(c0); n32[i].q[4 * a + 1] = uint16_t(c1);
+                n32[i].q[4 * a + 2] = uint16_t(std::max(u0 - c0, c0 - l0)); n32[i].q[4 * a + 3] = uint16_t(std::max(u1 - c1, c1 - l1));
             }
             n32[i].child0 = nd.child0; n32[i].child1 = nd.child1;
         }
