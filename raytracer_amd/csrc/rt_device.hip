@@ -687,7 +687,7 @@ constexpr int kBlockLds = 512;      // workgroup of the LDS-resident kernel: 2 p
 constexpr int kTravThreshold = 12;
 constexpr int kMaxWide = 4;         // spheres kept out of the tree at most (tested linearly per segment)
 constexpr int kInnerThreshold = 8;
-constexpr int kLeaveThreshold = 20;  // lanes that may leave the inner nodes before the wave turns to the leaves
+constexpr int kLeaveThreshold = 48;  // lanes that may leave the inner nodes before the wave turns to the leaves (measured flat from 40 up: with the short inner step a run is best ended by kInnerThreshold alone)
 
 struct Node16 {       // 32 bytes: two 16-byte LDS reads
     uint16_t h[12];   // IEEE half bits; per axis x, y, z: centre of child 0, of child 1, half extent of child 0, of child 1
