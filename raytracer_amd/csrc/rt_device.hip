@@ -1135,16 +1135,6 @@ __device__ __forceinline__ void leaf_step(const Tables& Tb, const Path& p, Trav&
 constexpr int kModeProduction = 0, kModeStats = 1, kModeDump = 2, kModeTiming = 3;
 
 __device__ __forceinline__ uint64_t cycle_stamp() { return __builtin_amdgcn_s_memtime(); }
-// issue priority of this wave among the waves of its SIMD (s_setprio takes an immediate)
-__device__ __forceinline__ void set_wave_priority(uint32_t p) {
-    switch (p & 3u) {
-    case 0: __builtin_amdgcn_s_setprio(0); break;
-    case 1: __builtin_amdgcn_s_setprio(1); break;
-    case 2: __builtin_amdgcn_s_setprio(2); break;
-    default: __builtin_amdgcn_s_setprio(3); break;
-    }
-}
-
 template <bool LDS16, int BLOCK, int MODE>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void render_kernel_ws(SceneDev S, CamDev C, RenderParams P,
                                                           const Node16* __restrict__ nodes16, uint32_t stack_depth,
@@ -1206,11 +1196,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     const int leave_threshold = int(P.leave_threshold);
     const uint32_t q0_addr = lds_address(lds_q0), q1_addr = lds_address(lds_q1);
     const uint32_t slot1_addr = lds_address(stk) + uint32_t(BLOCK * sizeof(int32_t));
-    const uint32_t prio_inner = (P.flags >> 16) & 3u, prio_leaf = (P.flags >> 18) & 3u, prio_shade = (P.flags >> 20) & 3u;
-    const bool prio_used = (P.flags >> 16) & 63u;
 
     for (;;) {
-        if (prio_used) set_wave_priority(prio_shade);
         // ---- shade phase: every lane that is not descending.  One Philox block per lane and turn:
         // a path that scatters on draws (pixel, sample, bounce, 0), a path that ends makes room for
         // the pixel's next sample, whose camera ray draws (pixel, sample, 0, 0).
@@ -1288,7 +1275,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
             const int run_threshold = max(inner_threshold, int(__popcll(__ballot(T.node >= 0))) - leave_threshold);
             const uint64_t t_inner = TIMING ? cycle_stamp() : 0;
             if (TIMING) cyc[1] += t_inner - t_head;
-            if (prio_used) set_wave_priority(prio_inner);
             if (LDS16 && !STATS) {
                 inner_loop_lds16<BLOCK>(T, q0_addr, q1_addr, run_threshold);
             } else if (!STATS) {
@@ -1303,7 +1289,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
             }
             const uint64_t t_leaf = TIMING ? cycle_stamp() : 0;
             if (TIMING) cyc[2] += t_leaf - t_inner;
-            if (prio_used) set_wave_priority(prio_leaf);
             if (STATS && __any(T.node < 0 && T.node != kLeafSentinel)) { st[2]++; if (T.node < 0 && T.node != kLeafSentinel) st[3]++; }
             if (T.node < 0 && T.node != kLeafSentinel) leaf_step<LDS16, BLOCK>(Tb, p, T);
             if (TIMING) cyc[3] += cycle_stamp() - t_leaf;
@@ -1618,8 +1603,6 @@ RenderParams make_params(const rt_camera& cam, const rt_render_opts& o, uint32_t
     if (const char* e = std::getenv("RT_TRAV_THRESHOLD")) P.trav_threshold = uint32_t(std::atoi(e));    // tuning aid
     if (const char* e = std::getenv("RT_LEAVE_THRESHOLD")) P.leave_threshold = uint32_t(std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("RT_INNER_THRESHOLD")) P.inner_threshold = uint32_t(std::max(1, std::atoi(e)));
-    // tuning aid: issue priorities of the three phases, two bits each (inner loop | leaf turn << 2 | shade << 4)
-    if (const char* e = std::getenv("RT_PHASE_PRIORITY")) P.flags |= (uint32_t(std::atoi(e)) & 63u) << 16;
     return P;
 }
 
