@@ -686,6 +686,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(SceneDev S, CamDev C, Re
 constexpr int kBlockLds = 512;      // workgroup of the LDS-resident kernel: 2 per CU = 16 waves = 4 per SIMD (128 VGPRs)
 constexpr int kTravThreshold = 12;
 constexpr int kMaxWide = 4;         // spheres kept out of the tree at most (tested linearly per segment)
+constexpr int kSmallScene = 12;     // up to this many spheres no tree is built at all: every sphere is tested per segment
 constexpr int kInnerThreshold = 8;
 constexpr int kLeaveThreshold = 48;  // lanes that may leave the inner nodes before the wave turns to the leaves (measured flat from 40 up: with the short inner step a run is best ended by kInnerThreshold alone)
 
@@ -1434,7 +1435,8 @@ struct rt_scene {
     uint32_t* d_work_counter = nullptr;
     float* d_partials = nullptr;        // partial-sum slots of chunked renders, grown on demand
     size_t partials_bytes = 0;
-    const Node16* d_nodes16 = nullptr;  // f16 copy of the nodes for the LDS-resident kernel, or null
+    const Node16* d_nodes16 = nullptr;  // f16 copy of the nodes for the LDS-resident kernel (null when it has none)
+    bool lds_scene = false;             // the render kernel stages nodes and primitive tables in LDS
     size_t lds16_scene_bytes = 0;
     uint32_t stack_depth = 0;
     int n_cu = 0;
@@ -1712,6 +1714,10 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
         const double x = std::max(hi[0] - lo[0], 0.0), y = std::max(hi[1] - lo[1], 0.0), z = std::max(hi[2] - lo[2], 0.0);
         return x * y + y * z + z * x;
     };
+    // A handful of spheres (nested shells, the bundled scene.json) is cheaper to test one after the other while
+    // shading, where nearly all lanes of a wave take part, than through a descent whose inner and leaf turns run half
+    // empty: such a scene has no tree, like the reference's own linear path (src/lib.rs:46-49).
+    if (sphere_ids.size() <= size_t(kSmallScene)) { wide_ids = sphere_ids; tree_ids.clear(); }
     while (wide_ids.size() < size_t(kMaxWide) && tree_ids.size() >= 2) {
         size_t big = 0;
         double big_area = -1.0;
@@ -1869,6 +1875,7 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
             }
             if ((rc = upload(sc, n16, &sc->d_nodes16)) != RT_OK) return bail(rc);
             sc->lds16_scene_bytes = scene_bytes;
+            sc->lds_scene = true;
         }
     }
     {
@@ -1947,7 +1954,7 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
         return bail(fail(RT_ERR_DEVICE, "rt_scene_create: hipEventCreate failed"));
     {   // the production kernel's residency, asked here so that no render call has to
         int per_cu = 0;
-        if ((rc = resident_blocks(sc, false, sc->d_nodes16 != nullptr, kModeProduction, &per_cu)) != RT_OK) return bail(rc);
+        if ((rc = resident_blocks(sc, false, sc->lds_scene, kModeProduction, &per_cu)) != RT_OK) return bail(rc);
     }
 
     sc->info.n_hittables = n_hittables;
@@ -1957,7 +1964,7 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
     sc->info.bvh_depth = bvh.depth;
     sc->info.stack_depth = sc->stack_depth;
     sc->info.device = device;
-    sc->info.lds_resident = sc->d_nodes16 ? 1 : 0;
+    sc->info.lds_resident = sc->lds_scene ? 1 : 0;
     sc->info.n_wide = uint32_t(n_wide);
     sc->info.reserved = 0;
     sc->info.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -2014,7 +2021,7 @@ int launch_render(rt_scene* scene, const rt_camera* cam, const rt_render_opts* o
         if ((rc = resident_blocks(scene, true, false, 0, &per_cu)) != RT_OK) return rc;
         hipLaunchKernelGGL(render_kernel, grid_for(per_cu, kBlock), dim3(kBlock), stack_bytes(scene), st, S, C, P, depth_slots,
                            d_sum_rgb, d_partials, d_work_counter);
-    } else if (scene->d_nodes16 && !(opts->flags & RT_RENDER_KERNEL_NO_LDS_SCENE)) {
+    } else if (scene->lds_scene && !(opts->flags & RT_RENDER_KERNEL_NO_LDS_SCENE)) {
         if ((rc = resident_blocks(scene, false, true, mode, &per_cu)) != RT_OK) return rc;
         hipLaunchKernelGGL(ws_kernel(true, mode), grid_for(per_cu, kBlockLds), dim3(kBlockLds),
                            lds16_launch_bytes(scene->lds16_scene_bytes, scene->stack_depth), st, S, C, P, scene->d_nodes16, depth_slots,
@@ -2148,7 +2155,7 @@ int rt_debug_render_launch(rt_scene* scene, uint32_t* block_threads, uint32_t* w
     if (!scene || !block_threads || !workgroups_per_cu || !waves_per_simd) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_render_launch: null argument");
     DeviceGuard guard;
     RT_HIP(hipSetDevice(scene->device));
-    const bool lds16 = scene->d_nodes16 != nullptr;
+    const bool lds16 = scene->lds_scene;
     const int block = lds16 ? kBlockLds : kBlock;
     int per_cu = 0;
     if (int rc = resident_blocks(scene, false, lds16, kModeProduction, &per_cu)) return rc;

@@ -691,8 +691,11 @@ def test_wide_spheres_outside_the_tree(rt, ob):
     small = [rt.sphere(list(rng.uniform(-3, 3, 3)), 0.3, grey) for _ in range(30)]
     cases = {
         # name: (hittables, wide spheres expected)
-        "big_and_small": ([rt.sphere([0, 0, 0], 50.0, grey), rt.sphere([1, 0, 0], 0.5, grey)], 1),
-        "concentric_pair": ([rt.sphere([0, 0, 0], 2.0, grey), rt.sphere([0, 0, 0], 1.0, grey)], 1),
+        # up to a dozen spheres there is no tree at all: every sphere is tested per segment
+        "big_and_small": ([rt.sphere([0, 0, 0], 50.0, grey), rt.sphere([1, 0, 0], 0.5, grey)], 2),
+        "concentric_pair": ([rt.sphere([0, 0, 0], 2.0, grey), rt.sphere([0, 0, 0], 1.0, grey)], 2),
+        "a_dozen": (small[:12], 12),
+        "thirteen": (small[:13], 0),
         "three_shells_and_crowd": ([rt.sphere([0, 0, 0], 40.0, grey), rt.sphere([0, 0, 0], 30.0, rt.dielectric(1.5)),
                                     rt.sphere([0.5, 0, 0], 20.0, rt.dielectric(1.5))] + small, 3),
         "many_shells": ([rt.sphere([0, 0, 0], 10.0 + i, rt.dielectric(1.5)) for i in range(7)] + small, 4),  # at most four
