@@ -98,6 +98,12 @@ struct CamDev {
     uint32_t W, H;
 };
 
+// The render kernel keeps the camera in LDS: twenty scalar registers held across the whole loop for a block of code
+// that runs once per path cost more in register spills than five broadcast reads cost there.
+typedef __attribute__((address_space(3))) const CamDev lds_cam;
+constexpr uint32_t kCamLdsBytes = 96;
+static_assert(sizeof(CamDev) <= kCamLdsBytes, "camera copy in LDS");
+
 struct RenderParams {
     uint32_t sample_begin, sample_end, depth, flags;
     uint32_t key0, key1;
@@ -348,7 +354,9 @@ __device__ __forceinline__ void unit_f64(float x, float y, float z, double* X, d
 // src/camera.rs:49-78 + src/ray.rs:9-11 with the two rejection loops replaced
 // by direct draws of the same distributions (quarter disc, unit square).
 // r = Philox block (pixel, sample, 0, 0).
-__device__ __forceinline__ void camera_ray_from(const CamDev& C, uint32_t i, uint32_t j, const uint4 r, float o[3], float d[3]) {
+// CamT: CamDev (kernel argument, lives in scalar registers) or its copy in LDS (lds_cam below).
+template <class CamT>
+__device__ __forceinline__ void camera_ray_from(const CamT& C, uint32_t i, uint32_t j, const uint4 r, float o[3], float d[3]) {
 #pragma clang fp contract(off)
     const float rad = fast_sqrt(u01(r.x));
     float s, c;
@@ -369,7 +377,8 @@ __device__ __forceinline__ void camera_ray(const CamDev& C, const RenderParams& 
     camera_ray_from(C, pixel % C.W, pixel / C.W, philox4x32_10(pixel, sample, 0u, 0u, P.key0, P.key1), o, d);
 }
 
-__device__ __forceinline__ void start_path_from(const CamDev& C, uint32_t pixel, uint32_t px, uint32_t py, uint32_t sample,
+template <class CamT>
+__device__ __forceinline__ void start_path_from(const CamT& C, uint32_t pixel, uint32_t px, uint32_t py, uint32_t sample,
                                                 const uint4 r, Path& p) {
     float o[3], d[3];
     camera_ray_from(C, px, py, r, o, d);
@@ -1160,6 +1169,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     lds_u32* wave_state = (lds_u32*)(reinterpret_cast<uint32_t*>(stk0 + stack_depth * BLOCK) + 4 * (threadIdx.x >> 6));
     wave_state[0] = 0; wave_state[1] = 64; wave_state[2] = 0; wave_state[3] = 0;
     stk[0] = kLeafSentinel;
+    CamDev* cam_slot = reinterpret_cast<CamDev*>(reinterpret_cast<uint32_t*>(stk0 + stack_depth * BLOCK) + 4 * (BLOCK / 64));
+    if (threadIdx.x == 0) *cam_slot = C;
+    lds_cam& Cl = *(lds_cam*)cam_slot;
     if (LDS16) {
         const uint4* src = reinterpret_cast<const uint4*>(nodes16);
         for (int32_t i = threadIdx.x; i < S.n_nodes; i += BLOCK) { lds_q0[i] = src[2 * i]; lds_q1[i] = src[2 * i + 1]; }
@@ -1171,8 +1183,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         int32_t* kdst = reinterpret_cast<int32_t*>(lds_kind);
         int32_t* idst = reinterpret_cast<int32_t*>(lds_id);
         for (int32_t i = threadIdx.x; i < n_prims; i += BLOCK) { kdst[i] = S.kind[i]; idst[i] = S.prim_id[i]; }
-        __syncthreads();
     }
+    __syncthreads();
     const Tables Tb = LDS16 ? Tables{reinterpret_cast<const double4*>(lds_sph), reinterpret_cast<const float4*>(lds_mat),
                                      reinterpret_cast<const int32_t*>(lds_kind), reinterpret_cast<const int32_t*>(lds_id)}
                             : global_tables(S);
@@ -1252,7 +1264,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
             if (alive) {
                 const uint4 r = philox4x32_10(p.pixel, p.sample, fresh ? 0u : p.bounce, 0u, P.key0, P.key1);
                 if (fresh) {
-                    start_path_from(C, p.pixel, pix_xy & 0xffffu, pix_xy >> 16, p.sample, r, p);
+                    start_path_from(Cl, p.pixel, pix_xy & 0xffffu, pix_xy >> 16, p.sample, r, p);
                 } else if (!scatter_part(P, p, sf, r)) {
                     alive = false;  // bounded fuzz loop gave up: the path contributes nothing
                 }
@@ -1507,11 +1519,11 @@ float descent_eps(const rt_scene* sc, double origin_abs) {
 }
 
 // LDS of the 256-thread kernels: the traversal stack plus four words of pixel hand-out state per wave
-size_t stack_bytes(const rt_scene* sc) { return size_t(std::max<uint32_t>(sc->stack_depth, 1u)) * kBlock * sizeof(int32_t) + 64; }  // 16 bytes of hand-out state per wave
+size_t stack_bytes(const rt_scene* sc) { return size_t(std::max<uint32_t>(sc->stack_depth, 1u)) * kBlock * sizeof(int32_t) + 64 + kCamLdsBytes; }  // 16 bytes of hand-out state per wave, the camera
 
 // LDS of one workgroup of the LDS-resident kernel: scene tables, the stack columns of kBlockLds lanes, hand-out state
 size_t lds16_launch_bytes(size_t scene_bytes, uint32_t stack_depth) {
-    return scene_bytes + size_t(std::max<uint32_t>(stack_depth, 1u)) * kBlockLds * sizeof(int32_t) + 16 * (kBlockLds / 64);
+    return scene_bytes + size_t(std::max<uint32_t>(stack_depth, 1u)) * kBlockLds * sizeof(int32_t) + 16 * (kBlockLds / 64) + kCamLdsBytes;
 }
 constexpr size_t kLdsPerCu = 160 * 1024;
 

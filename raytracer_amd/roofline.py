@@ -16,6 +16,16 @@ SPHERE_BYTES = 16
 PEAK_FP32_TFLOPS = 157.3  # MI355X vector FP32: 1024 SIMDs x 32 lanes x 2 flop (plain v_fma_f32, one wave64 instruction per 2 cycles) x 2.4 GHz
 PEAK_HBM_GBS = 8000.0
 
+# What binds the descent of a tree that lives in HBM / the caches (1M spheres and up) is not HBM bandwidth — the nodes
+# a frame touches sit in L1 / L2 / Infinity Cache — but the rate at which a CU's vector memory path serves per-lane
+# gathers: every lane of a wave fetches its own 32-byte node (two 16-byte loads) per step.  Measured on one MI355X with
+# tools/microbench/gather_rate.hip (dependent random walks, 16 waves per CU, all 64 lanes on), in 1e9 node fetches
+# per second over the chip, by where the table lives:
+GATHER_GNODES_L1 = 925.0      # 32 KB table: every fetch hits the CU's L1 — the ceiling of the gather path itself
+GATHER_GNODES_L2 = 410.0      # 4 MB table: the XCD's L2
+GATHER_GNODES_MALL = 250.0    # 32 MB table: L2 misses served by the Infinity Cache (the rate does not depend on lanes on or waves)
+GATHER_GNODES_HBM = 195.0     # 256 MB table: beyond the Infinity Cache
+
 
 def flops_per_segment(n_spheres):
     return 2 * math.ceil(math.log2(max(n_spheres, 2))) * F_BOX + F_SPHERE + F_SHADE

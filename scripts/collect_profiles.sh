@@ -13,12 +13,15 @@ cp "$out/pmc/summary.txt" "$out/bench_pmc_summary.txt"
 timeout -k 10 300 python3 bench.py > "$out/bench.log" 2>&1 || { echo "bench failed"; tail -5 "$out/bench.log"; exit 1; }
 tail -n 1 "$out/bench.log" > "$out/bench_line.json"
 : > "$out/configs.jsonl"; : > "$out/configs_with_phase_stats.jsonl"; : > "$out/configs_with_phase_timing.jsonl"
-for c in c1 c2 c2d10 c3 c4 c5; do
+for c in c1 c2 c2d10 c3 c4 c5 c6; do
   timeout -k 10 200 python3 scripts/run_config.py $c --steps 5 2>/dev/null | tail -n 1 >> "$out/configs.jsonl" || { echo "config $c failed"; exit 1; }
-  timeout -k 10 200 python3 scripts/run_config.py $c --steps 1 --stats 2>/dev/null | tail -n 1 >> "$out/configs_with_phase_stats.jsonl" || { echo "config $c stats failed"; exit 1; }
+  ms=$(tail -n 1 "$out/configs.jsonl" | python3 -c "import sys,json; print(json.loads(sys.stdin.read())['kernel_ms'])")
+  timeout -k 10 200 python3 scripts/run_config.py $c --steps 1 --stats --kernel-ms $ms 2>/dev/null | tail -n 1 >> "$out/configs_with_phase_stats.jsonl" || { echo "config $c stats failed"; exit 1; }
   timeout -k 10 200 python3 scripts/run_config.py $c --steps 2 --timing 2>/dev/null | tail -n 1 >> "$out/configs_with_phase_timing.jsonl" || { echo "config $c timing failed"; exit 1; }
 done
 # counters of the other two kernels that matter: nested shells (scene in LDS, deep paths) and the 1M-sphere tree in HBM
 PMC_CMD="scripts/run_config.py c4 --steps 1" bash scripts/pmc_passes.sh "$out/pmc_c4" > "$out/pmc_c4.log" 2>&1 && cp "$out/pmc_c4/summary.txt" "$out/c4_pmc_summary_2launches.txt"
 PMC_CMD="scripts/run_config.py c5 --steps 1" bash scripts/pmc_passes.sh "$out/pmc_c5" > "$out/pmc_c5.log" 2>&1 && cp "$out/pmc_c5/summary.txt" "$out/c5_pmc_summary_2launches.txt"
+timeout -k 10 60 raytracer_amd/bin/instr_cost > "$out/instr_cost.txt" 2>&1 || echo "instr_cost failed"
+timeout -k 10 120 raytracer_amd/bin/gather_rate > "$out/gather_rate.txt" 2>&1 || echo "gather_rate failed"
 echo collected

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--builder", default="sah", choices=["sah", "lbvh"])
     ap.add_argument("--chunk", type=int, default=0, help="samples per work item (0 = chosen by the library)")
+    ap.add_argument("--kernel-ms", type=float, default=0.0, help="kernel time of an un-instrumented run, for the roofline of a --stats run")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -89,6 +90,25 @@ def main():
                         "leaf_lane_util": round(o[3] / max(o[2], 1), 3), "shade_lane_util": round(o[5] / max(o[4], 1), 3)}
         out["algorithmic_bytes_per_segment"] = roofline.bytes_per_segment(len(h))
         out["executed_node_bytes_per_path"] = round(o[1] / paths * 32 + o[3] / paths * 32, 1)  # 32-byte nodes (f16 in LDS or 16-bit grid in HBM), 32-byte spheres
+        segments = (o[5] - o[6]) / paths  # every shade visit of a live path closes one segment
+        out["segments_per_path"] = round(segments, 4)
+        # the roofline of the resource that binds this configuration; the rate is taken from an un-instrumented run
+        # of the same kernel (`--stats` slows it down), which the caller passes with --kernel-ms
+        ms = a.kernel_ms or out["kernel_ms"]
+        if int(info["lds_resident"]):
+            fpp = roofline.flops_per_path(len(h), segments)
+            ach = paths * fpp / (ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "valu", "achieved": round(ach, 3), "peak": roofline.PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / roofline.PEAK_FP32_TFLOPS, 4), "algorithmic_flops_per_path": round(fpp, 1), "kernel_ms": ms}
+        else:
+            ach = o[1] / (ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "l1-gather", "achieved": round(ach, 1), "peak": roofline.GATHER_GNODES_L1, "unit": "1e9 node fetches/s",
+                               "frac": round(ach / roofline.GATHER_GNODES_L1, 4), "kernel_ms": ms,
+                               "note": "per-lane 32-byte node gathers; peak = tools/microbench/gather_rate on an L1-resident table; "
+                                       "the same walk out of L2 / Infinity Cache / HBM reaches %g / %g / %g"
+                                       % (roofline.GATHER_GNODES_L2, roofline.GATHER_GNODES_MALL, roofline.GATHER_GNODES_HBM),
+                               "algorithmic_bytes_per_path": round(segments * roofline.bytes_per_segment(len(h)), 1),
+                               "algorithmic_TBps": round(paths * segments * roofline.bytes_per_segment(len(h)) / (ms * 1e-3) / 1e12, 2)}
     if a.timing:
         st = np.zeros(8, dtype=np.uint64)
         _abi.check(_abi.lib.rt_debug_render_stats(scene.handle, st.ctypes.data))
