@@ -334,7 +334,7 @@ struct Path {
 
 __device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
 #pragma clang fp contract(off)
-    float inv = rsqrtf(x * x + y * y + z * z);
+    float inv = __builtin_amdgcn_rsqf(x * x + y * y + z * z);  // one instruction: the squared length of a direction is no denormal
     x *= inv; y *= inv; z *= inv;
 }
 
@@ -355,8 +355,10 @@ __device__ __forceinline__ void unit_f64(float x, float y, float z, double* X, d
 // by direct draws of the same distributions (quarter disc, unit square).
 // r = Philox block (pixel, sample, 0, 0).
 // CamT: CamDev (kernel argument, lives in scalar registers) or its copy in LDS (lds_cam below).
+// camera_ray_raw leaves the direction as pixel - origin; Ray::new's normalisation is the caller's (the render kernel
+// shares it with the scatter step).
 template <class CamT>
-__device__ __forceinline__ void camera_ray_from(const CamT& C, uint32_t i, uint32_t j, const uint4 r, float o[3], float d[3]) {
+__device__ __forceinline__ void camera_ray_raw(const CamT& C, uint32_t i, uint32_t j, const uint4 r, float o[3], float d[3]) {
 #pragma clang fp contract(off)
     const float rad = fast_sqrt(u01(r.x));
     float s, c;
@@ -369,6 +371,11 @@ __device__ __forceinline__ void camera_ray_from(const CamT& C, uint32_t i, uint3
         o[a] = fmaf(lb, C.v[a], fmaf(la, C.h[a], C.lookfrom[a]));
         d[a] = fmaf(gv, C.v[a], fmaf(gh, C.h[a], C.lookat[a])) - o[a];
     }
+}
+
+template <class CamT>
+__device__ __forceinline__ void camera_ray_from(const CamT& C, uint32_t i, uint32_t j, const uint4 r, float o[3], float d[3]) {
+    camera_ray_raw(C, i, j, r, o, d);
     normalize3(d[0], d[1], d[2]);
 }
 
@@ -463,32 +470,30 @@ __device__ __forceinline__ bool hit_part(const SceneDev& S, const Tables& Tb, co
     sf.kind = kind_word & 0xff;
     sf.w = m.w;
     sf.ddn = fmaf(dzf, sf.nz, fmaf(dyf, sf.ny, dxf * sf.nx));
-    if (sf.kind == RT_MAT_EMITTER) {  // src/lib.rs:101-104: the throughput is dropped
-        const float c = fabsf(sf.ddn);
-        Lr = m.x * c; Lg = m.y * c; Lb = m.z * c;
-        return false;
-    }
-    float ar = m.x, ag = m.y, ab = m.z;
-    if (sf.kind == RT_MAT_DIELECTRIC) ar = ag = ab = 1.0f;  // src/materials.rs:56-58
-    if (sf.kind == RT_MAT_TEXTUREMAP) {
+    const bool glass = sf.kind == RT_MAT_DIELECTRIC;  // src/materials.rs:56-58
+    float ar = glass ? 1.0f : m.x, ag = glass ? 1.0f : m.y, ab = glass ? 1.0f : m.z;
+    if (sf.kind > RT_MAT_DIELECTRIC) {  // the two rare kinds share one branch
+        if (sf.kind == RT_MAT_EMITTER) {  // src/lib.rs:101-104: the throughput is dropped
+            const float c = fabsf(sf.ddn);
+            Lr = m.x * c; Lg = m.y * c; Lb = m.z * c;
+            return false;
+        }
         if (k < S.n_spheres) normalize3(lx, ly, lz);  // spheres: normalised, discs: as is (src/lib.rs:108-111)
         texture_albedo(S, kind_word >> 8, lx, ly, lz, &ar, &ag, &ab);
     }
     p.tr *= ar; p.tg *= ag; p.tb *= ab;
-    if (p.bounce >= P.depth) {  // src/lib.rs:134: depth exhausted returns the throughput
-        Lr = p.tr; Lg = p.tg; Lb = p.tb;
-        return false;
-    }
-    return true;
+    Lr = p.tr; Lg = p.tg; Lb = p.tb;  // src/lib.rs:134: depth exhausted returns the throughput
+    return p.bounce < P.depth;
 }
 
 // Second half: Material::scatter (src/materials.rs:80-130) + Ray::new.  r0 = Philox block
 // (pixel, sample, bounce, 0).  Returns false only when the bounded fuzz loop gives up.
-__device__ __forceinline__ bool scatter_part(const RenderParams& P, Path& p, const Surf& sf, const uint4 r0) {
+// scatter_raw: the scattered direction before Ray::new normalises it.
+__device__ __forceinline__ bool scatter_raw(const RenderParams& P, const Path& p, const Surf& sf, const uint4 r0, float& sx, float& sy,
+                                            float& sz) {
 #pragma clang fp contract(off)
     const float dxf = float(p.dx), dyf = float(p.dy), dzf = float(p.dz);
     const float nx = sf.nx, ny = sf.ny, nz = sf.nz, ddn = sf.ddn;
-    float sx, sy, sz;  // scattered direction before Ray::new normalises it
     if (sf.kind == RT_MAT_DIELECTRIC) {  // src/materials.rs:96-121
         const float inc_cos = ddn;
         const float px = fmaf(-inc_cos, nx, dxf), py = fmaf(-inc_cos, ny, dyf), pz = fmaf(-inc_cos, nz, dzf);
@@ -530,6 +535,12 @@ __device__ __forceinline__ bool scatter_part(const RenderParams& P, Path& p, con
             sx = nx + vx; sy = ny + vy; sz = nz + vz;
         }
     }
+    return true;
+}
+
+__device__ __forceinline__ bool scatter_part(const RenderParams& P, Path& p, const Surf& sf, const uint4 r0) {
+    float sx, sy, sz;
+    if (!scatter_raw(P, p, sf, r0, sx, sy, sz)) return false;
     normalize3(sx, sy, sz);  // Ray::new
     p.ox = sf.hx; p.oy = sf.hy; p.oz = sf.hz;
     unit_f64(sx, sy, sz, &p.dx, &p.dy, &p.dz);
@@ -557,14 +568,10 @@ __device__ __forceinline__ bool advance(const SceneDev& S, const RenderParams& P
 // item's own slot of the partial-sum buffer (combine_kernel adds the slots in chunk order).
 __device__ __forceinline__ void flush_item(const RenderParams& P, float* sum_rgb, float* partials, uint32_t pixel,
                                            uint32_t chunk, float ar, float ag, float ab) {
-    if (P.n_chunks == 1) {
-        float* out = sum_rgb + 3 * size_t(pixel);
-        if (P.flags & RT_RENDER_ACCUMULATE) { ar += out[0]; ag += out[1]; ab += out[2]; }
-        out[0] = ar; out[1] = ag; out[2] = ab;
-    } else {
-        float* out = partials + 3 * (size_t(chunk) * P.n_pixels + pixel);
-        out[0] = ar; out[1] = ag; out[2] = ab;
-    }
+    const bool single = P.n_chunks == 1;  // then chunk is 0 and the slot formula below is the pixel's place in the image
+    float* out = (single ? sum_rgb : partials) + 3 * (size_t(chunk) * P.n_pixels + pixel);
+    if (single && (P.flags & RT_RENDER_ACCUMULATE)) { ar += out[0]; ag += out[1]; ab += out[2]; }
+    out[0] = ar; out[1] = ag; out[2] = ab;
 }
 
 // Work hand-out.  A work item is one 8x8 pixel tile x one chunk of samples.  A wave draws an item from
@@ -579,41 +586,56 @@ __device__ __forceinline__ uint32_t uniform(uint32_t v) { return uint32_t(__buil
 
 __device__ __forceinline__ void claim_pixels(bool& need, bool& done, uint32_t& pixel, uint32_t& xy, uint32_t& chunk, lds_u32* ws,
                                              uint32_t* work_counter, const RenderParams& P, const CamDev& C) {
-    const uint32_t n_items = P.tiles_x * P.tiles_y * P.n_chunks;
-    const uint32_t lane = __lane_id();
     unsigned long long m = __ballot(need);
     if (m == 0) return;
-    uint32_t item = uniform(ws[0]), next = uniform(ws[1]), origin = uniform(ws[2]), item_chunk = uniform(ws[3]);
-    while (m) {
-        if (next >= 64u) {  // the tile is dealt out: draw the next item and decode it once for its 64 pixels
-            const int first = __ffsll((long long)m) - 1;
-            uint32_t w = 0;
-            if (int(lane) == first) w = atomicAdd(work_counter, 1u);
-            item = uint32_t(__builtin_amdgcn_readlane(int32_t(w), first));
-            next = 0;
-            if (item < n_items) {
-                const uint32_t tile = item / P.n_chunks;
-                const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
-                origin = (tx * 8u) | ((ty * 8u) << 16);
-                item_chunk = item - tile * P.n_chunks;
-            }
-        }
-        if (item >= n_items) {  // nothing left: remember it, so later calls cost no atomic
-            if (need) { done = true; need = false; }
-            item = 0xffffffffu;
-            next = 0;
-            break;
-        }
-        const uint32_t rank = uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
-        const uint32_t avail = 64u - next;
-        if (need && rank < avail) {
-            const uint32_t in_tile = next + rank;  // row-major inside the tile
-            const uint32_t x = (origin & 0xffffu) + (in_tile & 7u);
+    const uint32_t lane = __lane_id();
+    uint32_t next = uniform(ws[1]), origin = uniform(ws[2]), item_chunk = uniform(ws[3]);
+    // The usual case by far: the wave's current tile still holds a pixel for every lane that asks.  One pass, no
+    // loop, only the tile's fill mark goes back to LDS.  (An exhausted wave keeps next = 64, so it never comes here.)
+    const uint32_t asked = uint32_t(__popcll(m));
+    if (next + asked <= 64u) {
+        if (need) {
+            const uint32_t in_tile = next + __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+            const uint32_t x = (origin & 0xffffu) + (in_tile & 7u);  // row-major inside the tile
             const uint32_t y = (origin >> 16) + (in_tile >> 3);
             if (x < C.W && y < C.H) { pixel = y * C.W + x; xy = x | (y << 16); chunk = item_chunk; need = false; }  // outside the frame: ask again
         }
-        const uint32_t asked = uint32_t(__popcll(m));
-        next += asked < avail ? asked : avail;
+        next += asked;
+        ws[1] = next;
+        m = __ballot(need);
+        if (m == 0) return;
+    }
+    const uint32_t n_items = P.tiles_x * P.tiles_y * P.n_chunks;
+    uint32_t item = uniform(ws[0]);
+    while (m) {
+        if (next >= 64u) {  // the tile is dealt out: draw the next item and decode it once for its 64 pixels
+            if (item != 0xffffffffu) {  // unless an earlier call found the counter exhausted: later calls cost no atomic
+                const int first = __ffsll((long long)m) - 1;
+                uint32_t w = 0;
+                if (int(lane) == first) w = atomicAdd(work_counter, 1u);
+                item = uint32_t(__builtin_amdgcn_readlane(int32_t(w), first));
+            }
+            if (item >= n_items) {  // nothing left
+                if (need) { done = true; need = false; }
+                item = 0xffffffffu;
+                break;
+            }
+            next = 0;
+            const uint32_t tile = item / P.n_chunks;
+            const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+            origin = (tx * 8u) | ((ty * 8u) << 16);
+            item_chunk = item - tile * P.n_chunks;
+        }
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+        const uint32_t avail = 64u - next;
+        if (need && rank < avail) {
+            const uint32_t in_tile = next + rank;
+            const uint32_t x = (origin & 0xffffu) + (in_tile & 7u);
+            const uint32_t y = (origin >> 16) + (in_tile >> 3);
+            if (x < C.W && y < C.H) { pixel = y * C.W + x; xy = x | (y << 16); chunk = item_chunk; need = false; }
+        }
+        const uint32_t asked_now = uint32_t(__popcll(m));
+        next += asked_now < avail ? asked_now : avail;
         m = __ballot(need);
     }
     ws[0] = item; ws[1] = next; ws[2] = origin; ws[3] = item_chunk;
@@ -1263,12 +1285,27 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
             }
             if (alive) {
                 const uint4 r = philox4x32_10(p.pixel, p.sample, fresh ? 0u : p.bounce, 0u, P.key0, P.key1);
+                // the new segment's origin and raw direction from either source, then ONE copy of Ray::new's
+                // normalisation (the same arithmetic as start_path_from / scatter_part)
+                float d[3];
+                double ox, oy, oz;
                 if (fresh) {
-                    start_path_from(Cl, p.pixel, pix_xy & 0xffffu, pix_xy >> 16, p.sample, r, p);
-                } else if (!scatter_part(P, p, sf, r)) {
-                    alive = false;  // bounded fuzz loop gave up: the path contributes nothing
+                    float o[3];
+                    camera_ray_raw(Cl, pix_xy & 0xffffu, pix_xy >> 16, r, o, d);
+                    ox = double(o[0]); oy = double(o[1]); oz = double(o[2]);
+                    p.tr = p.tg = p.tb = 1.0f;
+                    p.bounce = 1;
+                } else {
+                    alive = scatter_raw(P, p, sf, r, d[0], d[1], d[2]);  // false: the bounded fuzz loop gave up, the path contributes nothing
+                    ox = sf.hx; oy = sf.hy; oz = sf.hz;
+                    ++p.bounce;
                 }
-                if (alive) trav_begin<!LDS16>(S, Tb, p, T, slot1_addr);
+                if (alive) {
+                    normalize3(d[0], d[1], d[2]);
+                    p.ox = ox; p.oy = oy; p.oz = oz;
+                    unit_f64(d[0], d[1], d[2], &p.dx, &p.dy, &p.dz);
+                    trav_begin<!LDS16>(S, Tb, p, T, slot1_addr);
+                }
             }
         }
         if (TIMING) cyc[0] += cycle_stamp() - t_shade;
