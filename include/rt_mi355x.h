@@ -188,7 +188,7 @@ int rt_scene_reserve(rt_scene* scene, const rt_camera* cam, const rt_render_opts
  * work counter and the partial sums of a chunked render live in a fixed array of RT_NOALLOC_SCRATCH_BYTES of
  * device memory that is part of the library's code object (one copy per GPU, held until the process ends), so the
  * call makes no hipMalloc / hipFree.  Limits: with samples_per_item given, the partial sums
- * (chunks * horiz_res * vert_res * 12 bytes, chunks > 1) must fit RT_NOALLOC_SCRATCH_BYTES - 256, else RT_ERR_LIMIT;
+ * (chunks * horiz_res * vert_res * 12 bytes, chunks > 1) must fit RT_NOALLOC_SCRATCH_BYTES - 2048, else RT_ERR_LIMIT;
  * with samples_per_item = 0 the library uses min(the chunk count of rt_render_chunk, what fits, at least 1), i.e.
  * samples per item = ceil(spp / that count), so large frames are summed in fewer, longer chunks than
  * rt_render_device would use (same image up to f32 summation order).  Every call on a GPU uses that GPU's one array:
@@ -215,8 +215,9 @@ int rt_debug_render_paths(rt_scene* scene, const rt_camera* cam, const rt_render
  * workgroups the runtime can keep resident per CU (registers and LDS), and the waves per SIMD that follow. */
 int rt_debug_render_launch(rt_scene* scene, uint32_t* block_threads, uint32_t* workgroups_per_cu, uint32_t* waves_per_simd);
 
-/* Chunk size rt_render_device uses for this frame and sample range (the summation order of the image). */
-int rt_render_chunk(const rt_camera* cam, const rt_render_opts* opts, uint32_t* samples_per_item);
+/* Chunk size rt_render_device uses for this scene, frame and sample range (the summation order of the image): a
+ * scene whose tree is read from HBM is rendered in chunks of two samples, one that sits in LDS in longer ones. */
+int rt_render_chunk(const rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, uint32_t* samples_per_item);
 
 /* (1/spp) * sum, then color_to_ppm (src/lib.rs:148-149, :186-192): device
  * buffers, n_pixels*3 channels. */

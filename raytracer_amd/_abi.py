@@ -126,7 +126,7 @@ PROTOTYPES = {
     "rt_debug_render_stats": (_i, [_vp, _vp]),
     "rt_debug_render_paths": (_i, [_vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts), _vp]),
     "rt_debug_render_launch": (_i, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
-    "rt_render_chunk": (_i, [C.POINTER(rt_camera), C.POINTER(rt_render_opts), C.POINTER(_u32)]),
+    "rt_render_chunk": (_i, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_render_opts), C.POINTER(_u32)]),
     "rt_finalize_device": (_i, [_vp, _vp, _sz, _u32, _vp, _vp]),
     "rt_render": (_i, [_vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts), _vp, _vp]),
     "rt_render_multi": (_i, [C.POINTER(_vp), _sz, C.POINTER(rt_camera), C.POINTER(rt_render_opts), _vp, _vp]),

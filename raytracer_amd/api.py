@@ -168,12 +168,11 @@ class Scene:
         o.samples_per_item = int(samples_per_item)
         return o
 
-    @staticmethod
-    def render_chunk(cam, spp, sample_begin=0, samples_per_item=0):
-        """Samples per work item (the image's summation order) for this frame and sample count."""
+    def render_chunk(self, cam, spp, sample_begin=0, samples_per_item=0):
+        """Samples per work item (the image's summation order) for this scene, frame and sample count."""
         o = Scene.opts(sample_begin, sample_begin + spp, 1, 0, 0, samples_per_item)
         out = C.c_uint32(0)
-        check(lib.rt_render_chunk(C.byref(cam.c), C.byref(o), C.byref(out)))
+        check(lib.rt_render_chunk(self.handle, C.byref(cam.c), C.byref(o), C.byref(out)))
         return out.value
 
     def render(self, cam, spp, depth=REFERENCE_DEPTH, seed=0, sample_begin=0, want_sum=True, want_rgb8=True, flags=0,

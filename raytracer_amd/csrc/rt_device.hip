@@ -582,6 +582,12 @@ __device__ __forceinline__ void flush_item(const RenderParams& P, float* sum_rgb
 // item per pixel and 100 samples each, a third of the launch was spent waiting for the last items.
 // The four words are wave-uniform: they are read once into scalar registers, updated there and written back once.
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
+// The items are dealt from kCounters counters, each on a cache line of its own (word kCounterWord0 + 32 * c of the
+// counter block; the block's first 256 bytes hold the diagnostic words): counter c hands out the items c, c + 8,
+// c + 16 ...  A wave starts with the counter of its workgroup's number and moves on to the next when one runs dry.
+// One word served all requests before; at ~90 per microsecond it was a fifth busy with 200 k items per frame and
+// the waves queued for it.
+constexpr uint32_t kCounters = 8, kCounterWord0 = 64, kCounterBlockBytes = 256 + kCounters * 128;
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return uint32_t(__builtin_amdgcn_readfirstlane(int32_t(v))); }
 
 __device__ __forceinline__ void claim_pixels(bool& need, bool& done, uint32_t& pixel, uint32_t& xy, uint32_t& chunk, lds_u32* ws,
@@ -606,18 +612,23 @@ __device__ __forceinline__ void claim_pixels(bool& need, bool& done, uint32_t& p
         if (m == 0) return;
     }
     const uint32_t n_items = P.tiles_x * P.tiles_y * P.n_chunks;
-    uint32_t item = uniform(ws[0]);
+    uint32_t source = uniform(ws[0]);  // counter in use | counters found dry in a row << 8; 0xffffffff = nothing left anywhere
     while (m) {
         if (next >= 64u) {  // the tile is dealt out: draw the next item and decode it once for its 64 pixels
-            if (item != 0xffffffffu) {  // unless an earlier call found the counter exhausted: later calls cost no atomic
+            uint32_t item = 0xffffffffu;
+            while (source != 0xffffffffu) {  // an exhausted wave skips this: later calls cost no atomic
+                const uint32_t c = source & 0xffu;
                 const int first = __ffsll((long long)m) - 1;
                 uint32_t w = 0;
-                if (int(lane) == first) w = atomicAdd(work_counter, 1u);
-                item = uint32_t(__builtin_amdgcn_readlane(int32_t(w), first));
-            }
-            if (item >= n_items) {  // nothing left
-                if (need) { done = true; need = false; }
+                if (int(lane) == first) w = atomicAdd(work_counter + kCounterWord0 + 32u * c, 1u);
+                item = uint32_t(__builtin_amdgcn_readlane(int32_t(w), first)) * kCounters + c;
+                if (item < n_items) { source = c; break; }
+                const uint32_t dry = (source >> 8) + 1u;
+                source = dry >= kCounters ? 0xffffffffu : (((c + 1u) % kCounters) | (dry << 8));
                 item = 0xffffffffu;
+            }
+            if (item == 0xffffffffu) {  // nothing left
+                if (need) { done = true; need = false; }
                 break;
             }
             next = 0;
@@ -638,7 +649,7 @@ __device__ __forceinline__ void claim_pixels(bool& need, bool& done, uint32_t& p
         next += asked_now < avail ? asked_now : avail;
         m = __ballot(need);
     }
-    ws[0] = item; ws[1] = next; ws[2] = origin; ws[3] = item_chunk;
+    ws[0] = source; ws[1] = next; ws[2] = origin; ws[3] = item_chunk;
 }
 
 // ---------------------------------------------------------------- kernels
@@ -653,7 +664,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(SceneDev S, CamDev C, Re
     extern __shared__ int32_t stack_lds[];
     int32_t* stk = stack_lds + threadIdx.x;
     lds_u32* wave_state = (lds_u32*)(reinterpret_cast<uint32_t*>(stack_lds + stack_depth * kBlock) + 4 * (threadIdx.x >> 6));
-    wave_state[0] = 0; wave_state[1] = 64; wave_state[2] = 0; wave_state[3] = 0;
+    wave_state[0] = blockIdx.x % kCounters; wave_state[1] = 64; wave_state[2] = 0; wave_state[3] = 0;
 
     Path p;
     p.ox = p.oy = p.oz = 0.0;
@@ -729,8 +740,10 @@ static_assert(sizeof(Node16) == 32, "Node16 must be 32 bytes");
 
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
+typedef float float2v __attribute__((ext_vector_type(2)));
 struct Trav {
     float inv[3], A[3], E[3];  // per axis: step / d, (base - origin) / d, eps / |d|  (see trav_begin)
+    float2v inv_abs[3], A_E[3];  // the same as pairs {inv, |inv|} and {A, E}: operands of the packed FMAs of inner_loop_hbm
     float tmax;
     int32_t node;
     uint32_t sp;  // LDS byte address of the next free slot of this lane's stack column (slots are BLOCK * 4 bytes apart)
@@ -805,6 +818,10 @@ __device__ __forceinline__ void trav_begin(const SceneDev& S, const Tables& Tb, 
         T.inv[a] = step * i;
         T.A[a] = rel * i;
         T.E[a] = S.eps_rel * fabsf(i);
+        if (GRID) {
+            T.inv_abs[a] = float2v{T.inv[a], fabsf(T.inv[a])};
+            T.A_E[a] = float2v{T.A[a], T.E[a]};
+        }
     }
     T.tmax = (T.best.k >= 0) ? float(T.best.t) * (1.0f + 4.0e-7f) : 3.0e38f;
 }
@@ -1016,7 +1033,8 @@ __device__ __forceinline__ void inner_loop_lds16(Trav& T, uint32_t q0_addr, uint
 }
 
 // The same loop for the tree in HBM (Node32: boxes as 16-bit grid indices, the grid folded into T.inv / T.A / T.B
-// by trav_begin<true>): two 16-byte global loads per node, 12 conversions + 12 FMAs instead of the 12 mixed FMAs.
+// by trav_begin<true>): two 16-byte global loads per node, 12 conversions + 6 packed FMAs (both children of an axis
+// at once; the pairs {inv, |inv|} and {A, E} are broadcast by op_sel) instead of the 12 mixed FMAs.
 // The node's byte offset (index * 32) is formed in 32 bits: rt_scene_create admits at most 2^26 spheres in a tree.
 template <int BLOCK>
 __device__ __forceinline__ void inner_loop_hbm(Trav& T, const Node32* nodes32, int32_t thr) {
@@ -1051,10 +1069,8 @@ __device__ __forceinline__ void inner_loop_hbm(Trav& T, const Node32* nodes32, i
         "v_cvt_f32_u32_sdwa v113, v120 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
         "v_cvt_f32_u32_sdwa v114, v121 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
         "v_cvt_f32_u32_sdwa v115, v121 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-        "v_fma_f32 v112, v112, %[ix], %[ax]\n\t"
-        "v_fma_f32 v113, v113, %[ix], %[ax]\n\t"
-        "v_fma_f32 v114, v114, |%[ix]|, %[ex]\n\t"
-        "v_fma_f32 v115, v115, |%[ix]|, %[ex]\n\t"
+        "v_pk_fma_f32 v[112:113], v[112:113], %[px], %[qx] op_sel_hi:[1,0,0]\n\t"   // centres * inv + A, both children
+        "v_pk_fma_f32 v[114:115], v[114:115], %[px], %[qx] op_sel:[0,1,1] op_sel_hi:[1,1,1]\n\t"   // half extents * |inv| + E
         "v_pk_add_f32 v[116:117], v[112:113], v[114:115] neg_lo:[0,1] neg_hi:[0,1]\n\t"   // near parameters
         "v_pk_add_f32 v[112:113], v[112:113], v[114:115]\n\t"   // far parameters
         // y: v122 = centres (child 0 | child 1), v123 = half extents
@@ -1062,10 +1078,8 @@ __device__ __forceinline__ void inner_loop_hbm(Trav& T, const Node32* nodes32, i
         "v_cvt_f32_u32_sdwa v115, v122 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
         "v_cvt_f32_u32_sdwa v120, v123 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
         "v_cvt_f32_u32_sdwa v121, v123 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-        "v_fma_f32 v114, v114, %[iy], %[ay]\n\t"
-        "v_fma_f32 v115, v115, %[iy], %[ay]\n\t"
-        "v_fma_f32 v120, v120, |%[iy]|, %[ey]\n\t"
-        "v_fma_f32 v121, v121, |%[iy]|, %[ey]\n\t"
+        "v_pk_fma_f32 v[114:115], v[114:115], %[py], %[qy] op_sel_hi:[1,0,0]\n\t"   // centres * inv + A, both children
+        "v_pk_fma_f32 v[120:121], v[120:121], %[py], %[qy] op_sel:[0,1,1] op_sel_hi:[1,1,1]\n\t"   // half extents * |inv| + E
         "v_pk_add_f32 v[118:119], v[114:115], v[120:121] neg_lo:[0,1] neg_hi:[0,1]\n\t"   // near parameters
         "v_pk_add_f32 v[114:115], v[114:115], v[120:121]\n\t"   // far parameters
         // z: v124 = centres (child 0 | child 1), v125 = half extents
@@ -1073,10 +1087,8 @@ __device__ __forceinline__ void inner_loop_hbm(Trav& T, const Node32* nodes32, i
         "v_cvt_f32_u32_sdwa v121, v124 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
         "v_cvt_f32_u32_sdwa v122, v125 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
         "v_cvt_f32_u32_sdwa v123, v125 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-        "v_fma_f32 v120, v120, %[iz], %[az]\n\t"
-        "v_fma_f32 v121, v121, %[iz], %[az]\n\t"
-        "v_fma_f32 v122, v122, |%[iz]|, %[ez]\n\t"
-        "v_fma_f32 v123, v123, |%[iz]|, %[ez]\n\t"
+        "v_pk_fma_f32 v[120:121], v[120:121], %[pz], %[qz] op_sel_hi:[1,0,0]\n\t"   // centres * inv + A, both children
+        "v_pk_fma_f32 v[122:123], v[122:123], %[pz], %[qz] op_sel:[0,1,1] op_sel_hi:[1,1,1]\n\t"   // half extents * |inv| + E
         "v_pk_add_f32 v[124:125], v[120:121], v[122:123]\n\t"   // far parameters
         "v_pk_add_f32 v[122:123], v[120:121], v[122:123] neg_lo:[0,1] neg_hi:[0,1]\n\t"   // near parameters
         // near x / y / z = v116,117 / v118,119 / v122,123; far = v112,113 / v114,115 / v124,125 (child 0, child 1)
@@ -1139,8 +1151,8 @@ __device__ __forceinline__ void inner_loop_hbm(Trav& T, const Node32* nodes32, i
         "s_mov_b64 exec, s[88:89]\n\t"
         "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
         : [node] "+v"(T.node), [sp] "+v"(T.sp), [top] "+v"(T.top), [cnt] "=&s"(lanes_on_inner)
-        : [ix] "v"(T.inv[0]), [iy] "v"(T.inv[1]), [iz] "v"(T.inv[2]), [ax] "v"(T.A[0]), [ay] "v"(T.A[1]),
-          [az] "v"(T.A[2]), [ex] "v"(T.E[0]), [ey] "v"(T.E[1]), [ez] "v"(T.E[2]), [tmax] "v"(T.tmax),
+        : [px] "v"(T.inv_abs[0]), [py] "v"(T.inv_abs[1]), [pz] "v"(T.inv_abs[2]), [qx] "v"(T.A_E[0]), [qy] "v"(T.A_E[1]),
+          [qz] "v"(T.A_E[2]), [tmax] "v"(T.tmax),
           [base] "s"(base), [thr] "s"(thr), [sentinel] "s"(kLeafSentinel),
           [stride] "s"(uint32_t(BLOCK * sizeof(int32_t)))
         : "memory", "vcc", "scc", "v112", "v113", "v114", "v115", "v116", "v117",
@@ -1163,7 +1175,8 @@ __device__ __forceinline__ void leaf_step(const Tables& Tb, const Path& p, Trav&
 //   kModeDump    the production code (assembly loops included) that also stores every finished path's colour to
 //                dump[(pixel * spp + sample - sample_begin) * 3]: what the parity tests compare path by path
 //   kModeTiming  the production code with a cycle stamp around every phase; one lane per wave adds, to the same
-//                eight words, {shade, descent-loop header, inner loop, leaf turn, whole kernel} cycles, waves, 0, 0
+//                eight words, {shade, descent-loop header, inner loop, leaf turn, whole kernel} cycles, waves, and the
+//                two parts of the shade time spent {closing segments (hit_part), ending paths (flush, hand-out)}
 constexpr int kModeProduction = 0, kModeStats = 1, kModeDump = 2, kModeTiming = 3;
 
 __device__ __forceinline__ uint64_t cycle_stamp() { return __builtin_amdgcn_s_memtime(); }
@@ -1174,7 +1187,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                                                           uint32_t* __restrict__ work_counter, float* __restrict__ dump) {
     constexpr bool STATS = MODE == kModeStats, TIMING = MODE == kModeTiming, DUMP = MODE == kModeDump;
     uint32_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t cyc[5] = {0, 0, 0, 0, 0};
+    uint64_t cyc[7] = {0, 0, 0, 0, 0, 0, 0};
     const uint64_t t_begin = TIMING ? cycle_stamp() : 0;
     extern __shared__ uint4 lds_raw[];
     // LDS layout (16-byte units): [q0: n_nodes][q1: n_nodes][spheres: 2*n_spheres][mat: n_prims]
@@ -1189,7 +1202,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     int32_t* stk0 = reinterpret_cast<int32_t*>(lds_id + (LDS16 ? quads : 0));
     int32_t* stk = stk0 + threadIdx.x;
     lds_u32* wave_state = (lds_u32*)(reinterpret_cast<uint32_t*>(stk0 + stack_depth * BLOCK) + 4 * (threadIdx.x >> 6));
-    wave_state[0] = 0; wave_state[1] = 64; wave_state[2] = 0; wave_state[3] = 0;
+    wave_state[0] = blockIdx.x % kCounters; wave_state[1] = 64; wave_state[2] = 0; wave_state[3] = 0;
     stk[0] = kLeafSentinel;
     CamDev* cam_slot = reinterpret_cast<CamDev*>(reinterpret_cast<uint32_t*>(stk0 + stack_depth * BLOCK) + 4 * (BLOCK / 64));
     if (threadIdx.x == 0) *cam_slot = C;
@@ -1223,7 +1236,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     T.tmax = 0.0f;
     T.best.t = 0.0; T.best.k = -1; T.best.id = 0;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { T.inv[a] = 0.0f; T.A[a] = 0.0f; T.E[a] = 0.0f; }
+    for (int a = 0; a < 3; ++a) { T.inv[a] = 0.0f; T.A[a] = 0.0f; T.E[a] = 0.0f; T.inv_abs[a] = float2v{0.0f, 0.0f}; T.A_E[a] = float2v{0.0f, 0.0f}; }
     bool have_pixel = false, alive = false, done = false;
     uint32_t next_sample = 0, item_end = 0, chunk = 0, pix_xy = 0;
     float ar = 0.0f, ag = 0.0f, ab = 0.0f;
@@ -1253,6 +1266,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                     }
                 }
             }
+            const uint64_t t_end = TIMING ? cycle_stamp() : 0;
+            if (TIMING) cyc[5] += t_end - t_shade;
             if (!alive) {
                 if (have_pixel && next_sample >= item_end) {
                     flush_item(P, sum_rgb, partials, p.pixel, chunk, ar, ag, ab);
@@ -1283,6 +1298,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                     ++next_sample;
                 }
             }
+            if (TIMING) cyc[6] += cycle_stamp() - t_end;
             if (alive) {
                 const uint4 r = philox4x32_10(p.pixel, p.sample, fresh ? 0u : p.bounce, 0u, P.key0, P.key1);
                 // the new segment's origin and raw direction from either source, then ONE copy of Ray::new's
@@ -1355,6 +1371,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 #pragma unroll
         for (int i = 0; i < 5; ++i) atomicAdd(out + i, (unsigned long long)cyc[i]);
         atomicAdd(out + 5, 1ull);
+        atomicAdd(out + 6, (unsigned long long)cyc[5]);
+        atomicAdd(out + 7, (unsigned long long)cyc[6]);
     }
 }
 
@@ -1463,8 +1481,8 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const float* __restric
     rgb8[g] = q;
 }
 
-// Scratch of rt_render_device_noalloc: the first 256 bytes are the work counter (and the words of the diagnostic
-// builds), the rest holds the partial sums of chunked renders.  One copy per GPU the library runs on, for the life of
+// Scratch of rt_render_device_noalloc: the first 2048 bytes are the counter block (the words of the diagnostic
+// builds and the work counters), the rest holds the partial sums of chunked renders.  One copy per GPU the library runs on, for the life of
 // the process.  In host code this name is only a handle for hipGetSymbolAddress, never a device address.
 static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
 
@@ -1624,7 +1642,8 @@ int check_render_args(const rt_scene* scene, const rt_camera* cam, const rt_rend
     return RT_OK;
 }
 
-RenderParams make_params(const rt_camera& cam, const rt_render_opts& o, uint32_t max_chunks = 64) {
+// tree_in_hbm: the render kernel will gather its nodes from memory (see chunk rule below)
+RenderParams make_params(const rt_camera& cam, const rt_render_opts& o, bool tree_in_hbm, uint32_t max_chunks = 64) {
     RenderParams P;
     P.sample_begin = o.sample_begin;
     P.sample_end = o.sample_end;
@@ -1635,14 +1654,22 @@ RenderParams make_params(const rt_camera& cam, const rt_render_opts& o, uint32_t
     P.n_pixels = cam.horiz_res * cam.vert_res;
     P.tiles_x = (cam.horiz_res + 7) / 8;
     P.tiles_y = (cam.vert_res + 7) / 8;
-    // enough items to keep every lane of the chip busy to the end: about 50 tile items per resident wave
-    // (measured at 1080p/100 spp: chunks of 25 samples 13.2 ms, 17-20 samples 12.4 ms, 10 samples 13.0 ms, 4 samples
-    // 15.5 ms; at 2160p/125 spp one chunk 59.3 ms, two or three 58.0 ms)
+    // Scene in LDS: enough items to keep every lane of the chip busy to the end, about 70 tile items per resident
+    // wave (measured at 1080p/100 spp with eight work counters: chunks of 17 samples 10.94 ms, 12 samples 10.82 ms,
+    // 9 samples 10.93 ms, 4 samples 11.1 ms; at 2160p/125 spp flat from 63 down to 21).
+    // Tree in HBM: chunks of two samples.  Lanes that draw pixels together get neighbours of one tile, and for as long
+    // as they stay together their camera rays walk the same nodes, so a wave's 64 gathers fall into few cache lines;
+    // every chunk boundary brings the wave's lanes together again (1 M spheres, 1080p/64 spp: chunks of 11 samples
+    // 28.9 ms, 4 samples 26.3 ms, 2 samples 25.9 ms, 1 sample 26.2 ms; 7.8 M spheres/16 spp: 16 samples 15.0 ms,
+    // 4 samples 10.0 ms, 1 sample 8.5 ms).
     const uint32_t spp = o.sample_end - o.sample_begin;
     if (o.samples_per_item) {
         P.chunk_spp = std::min<uint32_t>(o.samples_per_item, spp);
+    } else if (tree_in_hbm) {
+        const uint32_t cap = std::max<uint32_t>(max_chunks, 1u);
+        P.chunk_spp = std::min<uint32_t>(spp, std::max<uint32_t>(2u, (spp + cap - 1) / cap));
     } else {
-        const uint64_t want_items = 13000000, px = std::max<uint32_t>(P.n_pixels, 1);  // pixel chunks = 64 x tile items
+        const uint64_t want_items = 18000000, px = std::max<uint32_t>(P.n_pixels, 1);  // pixel chunks = 64 x tile items
         uint32_t chunks = uint32_t(std::min<uint64_t>(std::max<uint64_t>(1, (want_items + px / 2) / px), std::max<uint32_t>(max_chunks, 1u)));
         chunks = std::max<uint32_t>(1, std::min<uint32_t>(chunks, spp));
         P.chunk_spp = (spp + chunks - 1) / chunks;
@@ -1993,7 +2020,7 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
     }
     {
         void* p = nullptr;
-        if (hipMalloc(&p, 256) != hipSuccess) return bail(fail(RT_ERR_DEVICE, "rt_scene_create: hipMalloc of the work counter failed"));
+        if (hipMalloc(&p, kCounterBlockBytes) != hipSuccess) return bail(fail(RT_ERR_DEVICE, "rt_scene_create: hipMalloc of the work counter failed"));
         sc->allocations.push_back(p);
         sc->d_work_counter = static_cast<uint32_t*>(p);
     }
@@ -2055,7 +2082,7 @@ int launch_render(rt_scene* scene, const rt_camera* cam, const rt_render_opts* o
     const uint64_t n_work = uint64_t(P.tiles_x) * P.tiles_y * 64u * P.n_chunks;
     // one render of a handle at a time on the device: they share the work counter and the partial sums
     RT_HIP(hipStreamWaitEvent(st, scene->ev_done, 0));
-    RT_HIP(hipMemsetAsync(d_work_counter, 0, 256, st));
+    RT_HIP(hipMemsetAsync(d_work_counter, 0, kCounterBlockBytes, st));
     auto grid_for = [&](int per_cu, int block) {
         uint64_t blocks = uint64_t(scene->n_cu) * uint64_t(per_cu < 1 ? 1 : per_cu);
         return dim3(uint32_t(std::min<uint64_t>(blocks, (n_work + block - 1) / block)));
@@ -2098,7 +2125,7 @@ int rt_scene_reserve(rt_scene* scene, const rt_camera* cam, const rt_render_opts
     if (rc != RT_OK) return rc;
     DeviceGuard guard;
     RT_HIP(hipSetDevice(scene->device));
-    return reserve_partials(scene, partials_needed(make_params(*cam, *opts)));
+    return reserve_partials(scene, partials_needed(make_params(*cam, *opts, !scene->lds_scene)));
 }
 
 int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, float* d_sum_rgb, void* stream) {
@@ -2108,8 +2135,8 @@ int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_render_opts
     DeviceGuard guard;
     RT_HIP(hipSetDevice(scene->device));
     // grown on first use unless rt_scene_reserve has sized it (the one case in which this call waits and allocates)
-    if ((rc = reserve_partials(scene, partials_needed(make_params(*cam, *opts)))) != RT_OK) return rc;
-    return launch_render(scene, cam, opts, make_params(*cam, *opts), d_sum_rgb, static_cast<hipStream_t>(stream), scene->d_work_counter,
+    if ((rc = reserve_partials(scene, partials_needed(make_params(*cam, *opts, !scene->lds_scene)))) != RT_OK) return rc;
+    return launch_render(scene, cam, opts, make_params(*cam, *opts, !scene->lds_scene), d_sum_rgb, static_cast<hipStream_t>(stream), scene->d_work_counter,
                          scene->d_partials, nullptr);
 }
 
@@ -2143,15 +2170,16 @@ int rt_render_device_noalloc(rt_scene* scene, const rt_camera* cam, const rt_ren
     RT_HIP(hipSetDevice(scene->device));
     unsigned char* base = nullptr;
     if ((rc = scratch_of_current_device(scene->device, &base)) != RT_OK) return rc;
-    constexpr size_t kHeader = 256, kPartialBytes = size_t(RT_NOALLOC_SCRATCH_BYTES) - kHeader;
+    static_assert(rt::kCounterBlockBytes <= 2048, "counter block inside the scratch header");
+    constexpr size_t kHeader = 2048, kPartialBytes = size_t(RT_NOALLOC_SCRATCH_BYTES) - kHeader;
     const size_t slot = size_t(cam->horiz_res) * cam->vert_res * 3 * sizeof(float);
-    RenderParams P = make_params(*cam, *opts);
+    RenderParams P = make_params(*cam, *opts, !scene->lds_scene);
     if (partials_needed(P) > kPartialBytes) {
         if (opts->samples_per_item)
             return fail(RT_ERR_LIMIT, "rt_render_device_noalloc: %u chunks of a %u x %u frame need %zu bytes of partial sums, the fixed scratch holds %zu",
                         P.n_chunks, cam->horiz_res, cam->vert_res, partials_needed(P), kPartialBytes);
         // chunk size left to the library: as many chunks as the scratch holds (one chunk needs no partial sums at all)
-        P = make_params(*cam, *opts, uint32_t(std::max<size_t>(kPartialBytes / slot, 1)));
+        P = make_params(*cam, *opts, !scene->lds_scene, uint32_t(std::max<size_t>(kPartialBytes / slot, 1)));
     }
     return launch_render(scene, cam, opts, P, d_sum_rgb, static_cast<hipStream_t>(stream), reinterpret_cast<uint32_t*>(base),
                          reinterpret_cast<float*>(base + kHeader), nullptr);
@@ -2167,7 +2195,7 @@ int rt_debug_render_paths(rt_scene* scene, const rt_camera* cam, const rt_render
     const size_t n_pixels = size_t(cam->horiz_res) * cam->vert_res;
     const size_t n_paths = n_pixels * (opts->sample_end - opts->sample_begin);
     if (n_paths > (size_t(1) << 28)) return fail(RT_ERR_LIMIT, "rt_debug_render_paths: more than 2^28 paths in one call");
-    if ((rc = reserve_partials(scene, partials_needed(make_params(*cam, *opts)))) != RT_OK) return rc;
+    if ((rc = reserve_partials(scene, partials_needed(make_params(*cam, *opts, !scene->lds_scene)))) != RT_OK) return rc;
     float *d_sum = nullptr, *d_dump = nullptr;
     RT_HIP(hipMalloc(reinterpret_cast<void**>(&d_sum), n_pixels * 3 * sizeof(float)));
     if (hipMalloc(reinterpret_cast<void**>(&d_dump), n_paths * 3 * sizeof(float)) != hipSuccess) {
@@ -2175,7 +2203,7 @@ int rt_debug_render_paths(rt_scene* scene, const rt_camera* cam, const rt_render
         return fail(RT_ERR_DEVICE, "rt_debug_render_paths: hipMalloc failed");
     }
     if (hipMemset(d_dump, 0, n_paths * 3 * sizeof(float)) != hipSuccess) rc = fail(RT_ERR_DEVICE, "rt_debug_render_paths: hipMemset failed");
-    if (rc == RT_OK) rc = launch_render(scene, cam, opts, make_params(*cam, *opts), d_sum, nullptr, scene->d_work_counter, scene->d_partials, d_dump);
+    if (rc == RT_OK) rc = launch_render(scene, cam, opts, make_params(*cam, *opts, !scene->lds_scene), d_sum, nullptr, scene->d_work_counter, scene->d_partials, d_dump);
     if (rc == RT_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(RT_ERR_DEVICE, "rt_debug_render_paths: kernel execution failed");
     if (rc == RT_OK && hipMemcpy(rgb, d_dump, n_paths * 3 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
         rc = fail(RT_ERR_DEVICE, "rt_debug_render_paths: download failed");
@@ -2184,10 +2212,10 @@ int rt_debug_render_paths(rt_scene* scene, const rt_camera* cam, const rt_render
     return rc;
 }
 
-int rt_render_chunk(const rt_camera* cam, const rt_render_opts* opts, uint32_t* samples_per_item) {
-    if (!cam || !opts || !samples_per_item) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_chunk: null argument");
+int rt_render_chunk(const rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, uint32_t* samples_per_item) {
+    if (!scene || !cam || !opts || !samples_per_item) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_chunk: null argument");
     if (opts->sample_end <= opts->sample_begin) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_chunk: empty sample range");
-    *samples_per_item = make_params(*cam, *opts).chunk_spp;
+    *samples_per_item = make_params(*cam, *opts, !scene->lds_scene).chunk_spp;
     return RT_OK;
 }
 
@@ -2493,7 +2521,7 @@ int rt_generate_primary(rt_scene* scene, const rt_camera* cam, uint64_t seed, ui
     if (hipMalloc(reinterpret_cast<void**>(&d_d), 3 * n * sizeof(float)) != hipSuccess) { (void)hipFree(d_o); return fail(RT_ERR_DEVICE, "rt_generate_primary: hipMalloc failed"); }
     rt_render_opts o{};
     o.sample_begin = sample_begin; o.sample_end = sample_end; o.depth = 1; o.flags = 0; o.seed = seed;
-    const RenderParams P = make_params(*cam, o);
+    const RenderParams P = make_params(*cam, o, false);
     hipLaunchKernelGGL(generate_primary_kernel, dim3(uint32_t((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr, make_cam(*cam), P,
                        pixel_begin, uint32_t(ns), uint32_t(n), d_o, d_d);
     int rc = RT_OK;
@@ -2554,12 +2582,12 @@ int rt_trace_path_segments(rt_scene* scene, const rt_camera* cam, const rt_rende
         const dim3 grid(uint32_t((n + kBlock - 1) / kBlock));
         if (rgb) {
             hipLaunchKernelGGL(trace_paths_kernel, grid, dim3(kBlock), stack_bytes(scene), nullptr, S, make_cam(*cam),
-                               make_params(*cam, o), d_p, d_s, uint32_t(n), d_rgb);
+                               make_params(*cam, o, false), d_p, d_s, uint32_t(n), d_rgb);
             chk(hipGetLastError(), "launch");
         }
         if (n_seg) {
             hipLaunchKernelGGL(path_segments_kernel, grid, dim3(kBlock), stack_bytes(scene), nullptr, S, make_cam(*cam),
-                               make_params(*cam, o), d_p, d_s, uint32_t(n), max_segments, d_sid, d_st, d_nseg);
+                               make_params(*cam, o, false), d_p, d_s, uint32_t(n), max_segments, d_sid, d_st, d_nseg);
             chk(hipGetLastError(), "launch");
         }
         chk(hipDeviceSynchronize(), "kernel");

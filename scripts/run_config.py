@@ -115,7 +115,8 @@ def main():
         o = st.astype(float)
         total = max(o[4], 1.0)
         out["timing"] = {"shade": round(o[0] / total, 4), "descent_header": round(o[1] / total, 4), "inner_loop": round(o[2] / total, 4),
-                         "leaf_turn": round(o[3] / total, 4), "waves": int(o[5]), "wave_cycles_per_path": round(total / (W * H * spp), 1)}
+                         "leaf_turn": round(o[3] / total, 4), "shade_close_segment": round(o[6] / total, 4), "shade_end_path": round(o[7] / total, 4),
+                         "waves": int(o[5]), "wave_cycles_per_path": round(total / (W * H * spp), 1)}
     print(json.dumps(out), flush=True)
 
 

@@ -30,7 +30,7 @@ def test_noalloc_render_equals_render_device_twice_in_a_row(rt):
 
     lib = _abi.lib
     scene = rt.Scene(rt.gen_scene(1))
-    limit = _abi.RT_NOALLOC_SCRATCH_BYTES - 256
+    limit = _abi.RT_NOALLOC_SCRATCH_BYTES - 2048
     # (frame, spp, samples per item or 0): first a chunked render that fills a good part of the scratch,
     # then a smaller one whose slots lie inside the first one's
     for (w, h, spp, spi) in ((800, 450, 16, 4), (320, 200, 12, 0)):
@@ -38,7 +38,7 @@ def test_noalloc_render_equals_render_device_twice_in_a_row(rt):
         st_a, a = _render(lib.rt_render_device_noalloc, scene, cam, spp, 50, 3, spi, rt)
         st_b, b = _render(lib.rt_render_device, scene, cam, spp, 50, 3, spi, rt)
         assert st_a == 0 and st_b == 0, lib.rt_last_error()
-        chunk = rt.Scene.render_chunk(cam, spp, samples_per_item=spi)
+        chunk = scene.render_chunk(cam, spp, samples_per_item=spi)
         assert -(-spp // chunk) * w * h * 12 <= limit and -(-spp // chunk) > 1  # chunked, and it fits: same chunking on both sides
         assert np.isfinite(a).all() and a.min() >= 0
         assert np.array_equal(a, b), "noalloc render differs from rt_render_device at %dx%d" % (w, h)
@@ -46,7 +46,7 @@ def test_noalloc_render_equals_render_device_twice_in_a_row(rt):
     cam = rt.default_camera(1280, 720)
     spp = 30
     fit = max(limit // (1280 * 720 * 12), 1)
-    assert -(-spp // rt.Scene.render_chunk(cam, spp)) > fit  # the usual chunking would not fit
+    assert -(-spp // scene.render_chunk(cam, spp)) > fit  # the usual chunking would not fit
     st_a, a = _render(lib.rt_render_device_noalloc, scene, cam, spp, 50, 5, 0, rt)
     st_b, b = _render(lib.rt_render_device, scene, cam, spp, 50, 5, -(-spp // fit), rt)
     assert st_a == 0 and st_b == 0 and np.array_equal(a, b)
