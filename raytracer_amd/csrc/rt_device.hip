@@ -110,6 +110,7 @@ struct RenderParams {
     uint32_t n_pixels, tiles_x, tiles_y;
     uint32_t trav_threshold, inner_threshold, leave_threshold;  // schedule of render_kernel_ws
     uint32_t n_chunks, chunk_spp;              // a work item = one 8x8 tile x one chunk of chunk_spp samples
+    uint32_t band_items;                       // items per work counter when each counter owns a contiguous band (0: interleaved)
 };
 
 // ---------------------------------------------------------------- Philox
@@ -621,8 +622,9 @@ __device__ __forceinline__ void claim_pixels(bool& need, bool& done, uint32_t& p
                 const int first = __ffsll((long long)m) - 1;
                 uint32_t w = 0;
                 if (int(lane) == first) w = atomicAdd(work_counter + kCounterWord0 + 32u * c, 1u);
-                item = uint32_t(__builtin_amdgcn_readlane(int32_t(w), first)) * kCounters + c;
-                if (item < n_items) { source = c; break; }
+                const uint32_t j = uint32_t(__builtin_amdgcn_readlane(int32_t(w), first));
+                item = P.band_items ? c * P.band_items + j : j * kCounters + c;
+                if (item < n_items && (!P.band_items || j < P.band_items)) { source = c; break; }
                 const uint32_t dry = (source >> 8) + 1u;
                 source = dry >= kCounters ? 0xffffffffu : (((c + 1u) % kCounters) | (dry << 8));
                 item = 0xffffffffu;
@@ -1675,6 +1677,14 @@ RenderParams make_params(const rt_camera& cam, const rt_render_opts& o, bool tre
         P.chunk_spp = (spp + chunks - 1) / chunks;
     }
     P.n_chunks = (spp + P.chunk_spp - 1) / P.chunk_spp;
+    // Tree in HBM: counter c owns the c-th eighth of the items, a band of the frame.  Workgroups go round the eight
+    // XCDs in launch order and start with counter (workgroup number mod 8), so an XCD's waves work on one band while it
+    // lasts and that band's part of the tree stays in the XCD's own L2 (7.8 M spheres: 8.9 -> 8.6 ms; 1 M: 26.0 -> 25.7).
+    // Scene in LDS: item i belongs to counter i mod 8, which spreads cheap and dear regions over all counters.
+    P.band_items = tree_in_hbm ? (P.tiles_x * P.tiles_y * P.n_chunks + kCounters - 1) / kCounters : 0;
+    if (const char* e = std::getenv("RT_BANDS")) {  // tuning aid
+        P.band_items = std::atoi(e) ? (P.tiles_x * P.tiles_y * P.n_chunks + kCounters - 1) / kCounters : 0;
+    }
     P.trav_threshold = kTravThreshold;
     P.inner_threshold = kInnerThreshold;
     P.leave_threshold = kLeaveThreshold;
