@@ -24,4 +24,5 @@ PMC_CMD="scripts/run_config.py c4 --steps 1" bash scripts/pmc_passes.sh "$out/pm
 PMC_CMD="scripts/run_config.py c5 --steps 1" bash scripts/pmc_passes.sh "$out/pmc_c5" > "$out/pmc_c5.log" 2>&1 && cp "$out/pmc_c5/summary.txt" "$out/c5_pmc_summary_2launches.txt"
 timeout -k 10 60 raytracer_amd/bin/instr_cost > "$out/instr_cost.txt" 2>&1 || echo "instr_cost failed"
 timeout -k 10 120 raytracer_amd/bin/gather_rate > "$out/gather_rate.txt" 2>&1 || echo "gather_rate failed"
+timeout -k 10 60 raytracer_amd/bin/inner_step > "$out/inner_step.txt" 2>&1 || echo "inner_step failed"
 echo collected

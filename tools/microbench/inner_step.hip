@@ -6,8 +6,7 @@
 //   1  without the exit test (v_cmp / s_bcnt1 / s_cmp / s_cbranch)
 //   2  without the push / pop bookkeeping
 //   3  without the scalar mask logic: the child is chosen by one v_cmp + v_cndmask
-//   4  arithmetic only: no LDS reads in the loop (the node stays in registers)
-//   5  the three compares first and the scalar logic spread between the vector instructions that follow
+//   4  the three compares first and the scalar logic spread between the vector instructions that follow
 //   hipcc --offload-arch=gfx950 -O2 -o inner_step inner_step.hip && ./inner_step
 #include <hip/hip_runtime.h>
 
@@ -132,8 +131,7 @@ __global__ void k_inner(unsigned long long* out, const uint4* tree, float seed) 
     if (VARIANT == 1) asm volatile(HEAD SLAB SELECT_SCALAR FETCH PUSH_POP COUNT OPERANDS);
     if (VARIANT == 2) asm volatile(HEAD SLAB SELECT_SCALAR EXIT_TEST FETCH COUNT OPERANDS);
     if (VARIANT == 3) asm volatile(HEAD SLAB SELECT_VECTOR EXIT_TEST FETCH PUSH_POP COUNT OPERANDS);
-    if (VARIANT == 4) asm volatile(HEAD SLAB SELECT_SCALAR EXIT_TEST PUSH_POP COUNT OPERANDS);
-    if (VARIANT == 5) asm volatile(HEAD SLAB SELECT_SPREAD EXIT_TEST FETCH PUSH_POP COUNT OPERANDS);
+    if (VARIANT == 4) asm volatile(HEAD SLAB SELECT_SPREAD EXIT_TEST FETCH PUSH_POP COUNT OPERANDS);
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if (node == 0x12345678 && sp == 7u && top == 3) out[1] = 1;
     if ((threadIdx.x & 63) == 0) atomicAdd(out, t1 - t0);
@@ -168,9 +166,9 @@ int main() {
     CHECK(hipMalloc(&d_tree, tree.size() * 4));
     CHECK(hipMemcpy(d_tree, tree.data(), tree.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMalloc(&d_out, 16));
-    const char* names[6] = {"loop as run", "no exit test", "no push/pop", "vector select", "no node fetch", "scalar logic spread"};
+    const char* names[5] = {"loop as run", "no exit test", "no push/pop", "vector select", "scalar logic spread"};
     std::printf("%-22s %14s %14s %14s   (SIMD cycles per step of one wave, 64 lanes on)\n", "variant", "1 wave/SIMD", "2 waves/SIMD", "4 waves/SIMD");
-    for (int v = 0; v < 6; ++v) {
+    for (int v = 0; v < 5; ++v) {
         double cyc[3];
         int slot = 0;
         for (int threads : {256, 512, 1024}) {
@@ -181,8 +179,7 @@ int main() {
                 case 1: hipLaunchKernelGGL(k_inner<1>, dim3(n_cu), dim3(threads), lds_bytes, 0, d_out, d_tree, 1.5f); break;
                 case 2: hipLaunchKernelGGL(k_inner<2>, dim3(n_cu), dim3(threads), lds_bytes, 0, d_out, d_tree, 1.5f); break;
                 case 3: hipLaunchKernelGGL(k_inner<3>, dim3(n_cu), dim3(threads), lds_bytes, 0, d_out, d_tree, 1.5f); break;
-                case 4: hipLaunchKernelGGL(k_inner<4>, dim3(n_cu), dim3(threads), lds_bytes, 0, d_out, d_tree, 1.5f); break;
-                default: hipLaunchKernelGGL(k_inner<5>, dim3(n_cu), dim3(threads), lds_bytes, 0, d_out, d_tree, 1.5f); break;
+                default: hipLaunchKernelGGL(k_inner<4>, dim3(n_cu), dim3(threads), lds_bytes, 0, d_out, d_tree, 1.5f); break;
             }
             CHECK(hipDeviceSynchronize());
             unsigned long long hh[2];
