@@ -1498,7 +1498,6 @@ using namespace rt;
 struct rt_scene {
     int device = 0;
     rt_scene_info info{};
-    std::vector<rt_hittable> hittables;
     SceneDev dev{};
     std::vector<void*> allocations;
     uint32_t* d_work_counter = nullptr;
@@ -1532,6 +1531,50 @@ uint16_t half_round_up(double x) {
         h = half_from_bits(b);
     }
     return half_bits(h);
+}
+
+// ---- scene tables made on the device (the tree of RT_BUILDER_LBVH_DEVICE never visits the host)
+// Node -> Node32 with the arithmetic of the host encoder in rt_scene_create_ex: indices chosen in f64 against the
+// f32 base and step, bounds rounded outward, then centre and half extent in grid units.
+__device__ __forceinline__ uint32_t grid_down(float v, float base, float step) {
+    if (!(v < 3.0e38f)) return 65535u;
+    double q = floor((double(v) - double(base)) / double(step));
+    q = fmin(fmax(q, 0.0), 65535.0);
+    while (q > 0.0 && double(base) + q * double(step) > double(v)) q -= 1.0;
+    return uint32_t(q);
+}
+__device__ __forceinline__ uint32_t grid_up(float v, float base, float step) {
+    if (!(v < 3.0e38f)) return 65535u;
+    double q = ceil((double(v) - double(base)) / double(step));
+    q = fmin(fmax(q, 0.0), 65535.0);
+    while (q < 65535.0 && double(base) + q * double(step) < double(v)) q += 1.0;
+    return uint32_t(q);
+}
+__global__ __launch_bounds__(kBlock) void encode32_kernel(const Node* __restrict__ nodes, uint32_t n, float3 base, float3 step,
+                                                          Node32* __restrict__ out) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const Node nd = nodes[i];
+    const float b[3] = {base.x, base.y, base.z}, st[3] = {step.x, step.y, step.z};
+    Node32 r;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const uint32_t l0 = grid_down(nd.lo0[a], b[a], st[a]), u0 = grid_up(nd.hi0[a], b[a], st[a]);
+        const uint32_t l1 = grid_down(nd.lo1[a], b[a], st[a]), u1 = grid_up(nd.hi1[a], b[a], st[a]);
+        const uint32_t c0 = (l0 + u0) / 2, c1 = (l1 + u1) / 2;
+        r.q[4 * a] = uint16_t(c0); r.q[4 * a + 1] = uint16_t(c1);
+        r.q[4 * a + 2] = uint16_t(max(u0 - c0, c0 - l0)); r.q[4 * a + 3] = uint16_t(max(u1 - c1, c1 - l1));
+    }
+    r.child0 = nd.child0; r.child1 = nd.child1;
+    out[i] = r;
+}
+// out[k] = in[order[k]] for the spheres of the tree (leaf order), the rest of the table as it is
+template <class T>
+__global__ __launch_bounds__(kBlock) void gather_kernel(const T* __restrict__ in, const uint32_t* __restrict__ order, uint32_t n_tree,
+                                                        uint32_t n_total, T* __restrict__ out) {
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n_total) return;
+    out[k] = in[k < n_tree ? order[k] : k];
 }
 
 template <class T>
@@ -1746,6 +1789,10 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
     if (!textures && n_textures) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: null textures");
     if (n_hittables > (size_t(1) << 30)) return fail(RT_ERR_LIMIT, "rt_scene_create: more than 2^30 hittables");
     auto t0 = std::chrono::steady_clock::now();
+    const bool laps = std::getenv("RT_CREATE_LAPS") != nullptr;  // measurement aid: time since entry at each stage, on stderr
+    auto lap = [&](const char* what) {
+        if (laps) std::fprintf(stderr, "[rt_scene_create] %-18s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    };
 
     // validate and split by shape (before any device work: a bad scene is reported as such on any machine)
     std::vector<uint32_t> sphere_ids, disc_ids;
@@ -1771,6 +1818,7 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
         if (!textures[i].rgb8 || textures[i].width == 0 || textures[i].height == 0)
             return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: texture %zu is empty", i);
 
+    lap("validated");
     int n_dev = rt_device_count();
     if (n_dev <= 0) return fail(RT_ERR_DEVICE, "rt_scene_create: no HIP device is visible");
     if (device < 0 || device >= n_dev) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: device %d of %d", device, n_dev);
@@ -1778,15 +1826,25 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
     DeviceGuard guard;
     rt_scene* sc = new rt_scene;
     sc->device = device;
-    sc->hittables.assign(hittables, hittables + n_hittables);
     auto bail = [&](int code) { rt_scene_destroy(sc); return code; };
     if (hipSetDevice(device) != hipSuccess) return bail(fail(RT_ERR_DEVICE, "rt_scene_create: hipSetDevice(%d) failed", device));
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return bail(fail(RT_ERR_DEVICE, "rt_scene_create: hipGetDeviceProperties failed"));
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return bail(fail(RT_ERR_DEVICE, "rt_scene_create: device %d is %s, this library is built for gfx950 only", device, prop.gcnArchName));
-    sc->n_cu = prop.multiProcessorCount;
+    {   // the device's architecture and CU count, asked once per device (the query takes milliseconds)
+        static std::mutex prop_mutex;
+        static std::vector<std::pair<std::string, int>> known;  // [device] = {architecture, CUs}
+        std::lock_guard<std::mutex> lock(prop_mutex);
+        if (known.size() <= size_t(device)) known.resize(size_t(device) + 1);
+        if (known[size_t(device)].first.empty()) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, device) != hipSuccess) return bail(fail(RT_ERR_DEVICE, "rt_scene_create: hipGetDeviceProperties failed"));
+            known[size_t(device)] = {std::string(prop.gcnArchName), prop.multiProcessorCount};
+        }
+        const std::string& arch = known[size_t(device)].first;
+        if (std::strncmp(arch.c_str(), "gfx950", 6) != 0)
+            return bail(fail(RT_ERR_DEVICE, "rt_scene_create: device %d is %s, this library is built for gfx950 only", device, arch.c_str()));
+        sc->n_cu = known[size_t(device)].second;
+    }
 
+    lap("device set");
     // Wide spheres: a sphere whose box covers at least half of the box around all the others (the ground sphere of
     // src/scenegen.rs:18-21 is the example) would be reached by nearly every ray whatever the tree looks like, and
     // its huge box would sit in the root.  Up to kMaxWide of them stay out of the tree and are tested once per
@@ -1804,48 +1862,92 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
     // shading, where nearly all lanes of a wave take part, than through a descent whose inner and leaf turns run half
     // empty: such a scene has no tree, like the reference's own linear path (src/lib.rs:46-49).
     if (sphere_ids.size() <= size_t(kSmallScene)) { wide_ids = sphere_ids; tree_ids.clear(); }
-    while (wide_ids.size() < size_t(kMaxWide) && tree_ids.size() >= 2) {
-        size_t big = 0;
-        double big_area = -1.0;
+    if (tree_ids.size() >= 2) {
+        // Candidates are taken largest box first, each judged against the box around all spheres still in the tree.
+        // Two passes over the scene whatever the outcome: the kMaxWide + 1 largest boxes, then the box around
+        // everything else; the box "around all the others" of a candidate is that box joined with the other candidates'.
+        const size_t n_cand = std::min<size_t>(size_t(kMaxWide) + 1, tree_ids.size());
+        std::vector<std::pair<double, size_t>> cand;  // (area, position in tree_ids), largest first, earlier position first on ties
         for (size_t i = 0; i < tree_ids.size(); ++i) {
             double lo[3], hi[3];
             box_of(tree_ids[i], lo, hi);
             const double area = half_area(lo, hi);
-            if (area > big_area) { big_area = area; big = i; }
+            if (cand.size() < n_cand || area > cand.back().first) {
+                auto pos = std::upper_bound(cand.begin(), cand.end(), area, [](double a, const std::pair<double, size_t>& c) { return a > c.first; });
+                cand.insert(pos, {area, i});
+                if (cand.size() > n_cand) cand.pop_back();
+            }
         }
-        double ulo[3] = {1e300, 1e300, 1e300}, uhi[3] = {-1e300, -1e300, -1e300};
+        std::vector<char> is_cand(tree_ids.size(), 0);
+        for (const auto& c : cand) is_cand[c.second] = 1;
+        double rlo[3] = {1e300, 1e300, 1e300}, rhi[3] = {-1e300, -1e300, -1e300};  // box around the non-candidates
         for (size_t i = 0; i < tree_ids.size(); ++i) {
-            if (i == big) continue;
+            if (is_cand[i]) continue;
             double lo[3], hi[3];
             box_of(tree_ids[i], lo, hi);
-            for (int a = 0; a < 3; ++a) { ulo[a] = std::min(ulo[a], lo[a]); uhi[a] = std::max(uhi[a], hi[a]); }
+            for (int a = 0; a < 3; ++a) { rlo[a] = std::min(rlo[a], lo[a]); rhi[a] = std::max(rhi[a], hi[a]); }
         }
-        double blo[3], bhi[3], ilo[3], ihi[3];
-        box_of(tree_ids[big], blo, bhi);
-        for (int a = 0; a < 3; ++a) { ilo[a] = std::max(blo[a], ulo[a]); ihi[a] = std::min(bhi[a], uhi[a]); }
-        const bool overlaps = ilo[0] <= ihi[0] && ilo[1] <= ihi[1] && ilo[2] <= ihi[2];
-        if (!overlaps || !(half_area(ilo, ihi) >= 0.5 * half_area(ulo, uhi))) break;
-        wide_ids.push_back(tree_ids[big]);
-        tree_ids.erase(tree_ids.begin() + long(big));
+        std::vector<size_t> taken;  // positions in tree_ids that become wide
+        for (size_t c = 0; c < cand.size() && taken.size() < size_t(kMaxWide) && tree_ids.size() - taken.size() >= 2; ++c) {
+            double ulo[3] = {rlo[0], rlo[1], rlo[2]}, uhi[3] = {rhi[0], rhi[1], rhi[2]};
+            for (size_t o = c + 1; o < cand.size(); ++o) {  // the candidates not yet judged are still in the tree
+                double lo[3], hi[3];
+                box_of(tree_ids[cand[o].second], lo, hi);
+                for (int a = 0; a < 3; ++a) { ulo[a] = std::min(ulo[a], lo[a]); uhi[a] = std::max(uhi[a], hi[a]); }
+            }
+            double blo[3], bhi[3], ilo[3], ihi[3];
+            box_of(tree_ids[cand[c].second], blo, bhi);
+            for (int a = 0; a < 3; ++a) { ilo[a] = std::max(blo[a], ulo[a]); ihi[a] = std::min(bhi[a], uhi[a]); }
+            const bool overlaps = ilo[0] <= ihi[0] && ilo[1] <= ihi[1] && ilo[2] <= ihi[2];
+            if (!overlaps || !(half_area(ilo, ihi) >= 0.5 * half_area(ulo, uhi))) break;
+            taken.push_back(cand[c].second);
+        }
+        if (!taken.empty()) {
+            std::vector<char> gone(tree_ids.size(), 0);
+            for (size_t t : taken) { gone[t] = 1; wide_ids.push_back(tree_ids[t]); }
+            size_t w = 0;
+            for (size_t i = 0; i < tree_ids.size(); ++i)
+                if (!gone[i]) tree_ids[w++] = tree_ids[i];
+            tree_ids.resize(w);
+        }
     }
     std::sort(wide_ids.begin(), wide_ids.end());
     // the assembly descent forms a node's byte offset (index * 32) in 32 bits
     if (tree_ids.size() > (size_t(1) << 26)) return bail(fail(RT_ERR_LIMIT, "rt_scene_create: more than 2^26 spheres in the tree"));
 
+    lap("wide chosen");
     // BVH over the other spheres
     std::vector<double> sph4(4 * tree_ids.size());
     for (size_t i = 0; i < tree_ids.size(); ++i) {
         const rt_hittable& h = hittables[tree_ids[i]];
         sph4[4 * i] = h.centre[0]; sph4[4 * i + 1] = h.centre[1]; sph4[4 * i + 2] = h.centre[2]; sph4[4 * i + 3] = h.radius;
     }
+    lap("sph4 filled");
     uint32_t lg = 0;
     while ((size_t(1) << lg) < tree_ids.size()) ++lg;
     BuiltBvh bvh;
-    if (builder == RT_BUILDER_LBVH_DEVICE) {
+    // RT_BUILDER_LBVH_DEVICE on a scene that cannot sit in LDS anyway: the tree, its quantised copy and the sphere
+    // tables are made on the device and stay there (bvh.nodes / bvh.leaf_order stay empty); smaller scenes come back
+    // to the host, which also encodes the f16 copy for the LDS-resident kernel.
+    constexpr size_t kResidentMin = 4096;
+    const bool resident = builder == RT_BUILDER_LBVH_DEVICE && tree_ids.size() >= kResidentMin;
+    double* d_build_sph = nullptr;    // the tree's spheres in tree_ids order
+    Node* d_tree_nodes = nullptr;
+    uint32_t* d_leaf_order = nullptr;  // leaf position -> index into tree_ids
+    if (resident) {
+        if (int brc = build_lbvh_resident(sph4.data(), tree_ids.size(), &d_build_sph, &d_tree_nodes, &d_leaf_order, &bvh.depth,
+                                          bvh.scene_lo, bvh.scene_hi))
+            return bail(brc);
+        for (void* p : {static_cast<void*>(d_build_sph), static_cast<void*>(d_tree_nodes), static_cast<void*>(d_leaf_order)})
+            sc->allocations.push_back(p);  // from here on rt_scene_destroy frees them
+        sc->info.device_bytes += (tree_ids.size() - 1) * sizeof(Node);
+    } else if (builder == RT_BUILDER_LBVH_DEVICE) {
         if (int brc = build_lbvh_device(sph4.data(), tree_ids.size(), &bvh)) return bail(brc);
     } else {
         build_bvh(sph4.data(), tree_ids.size(), lg + 7, &bvh);
     }
+    lap("tree built");
+    const size_t n_nodes = resident ? tree_ids.size() - 1 : bvh.nodes.size();
     sc->stack_depth = bvh.depth + 2;  // one pending entry per level, plus slot 0 (the sentinel below every stack)
     // bound = largest |coordinate| of any surface point: path origins lie on surfaces (the wide spheres' too), and the
     // origin widening of the f32 descent is sized from it
@@ -1885,7 +1987,8 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
     };
     const size_t n_tree = tree_ids.size(), n_wide = wide_ids.size();
     for (size_t k = 0; k < n_s; ++k) {
-        const uint32_t id = k < n_tree ? tree_ids[bvh.leaf_order[k]] : wide_ids[k - n_tree];
+        // (a tree that stays on the device: build order here, the device puts the tables into leaf order below)
+        const uint32_t id = k < n_tree ? tree_ids[resident ? k : bvh.leaf_order[k]] : wide_ids[k - n_tree];
         const rt_hittable& h = hittables[id];
         h_sph[k] = make_double4(h.centre[0], h.centre[1], h.centre[2], h.radius);
         fill_material(k, id);
@@ -1902,6 +2005,7 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
     }
     sc->bound_abs = bound;
 
+    lap("tables filled");
     // textures as RGBA8 so one texel is one aligned 4-byte load
     std::vector<TexImgDev> h_teximg(n_textures);
     for (size_t i = 0; i < n_textures; ++i) {
@@ -1916,14 +2020,23 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
     }
 
     int rc;
+    lap("textures");
     // box around every finite node box (the f32 boxes are rounded outward, so it may exceed the spheres' box by an ulp)
     double glo[3], ghi[3];
     for (int a = 0; a < 3; ++a) { glo[a] = bvh.scene_lo[a]; ghi[a] = bvh.scene_hi[a]; }
-    for (const Node& nd : bvh.nodes)
+    auto take_node = [&](const Node& nd) {
         for (int a = 0; a < 3; ++a) {
             if (nd.lo0[a] < 3.0e38f) { glo[a] = std::min(glo[a], double(nd.lo0[a])); ghi[a] = std::max(ghi[a], double(nd.hi0[a])); }
             if (nd.lo1[a] < 3.0e38f) { glo[a] = std::min(glo[a], double(nd.lo1[a])); ghi[a] = std::max(ghi[a], double(nd.hi1[a])); }
         }
+    };
+    if (resident) {  // the root's two boxes hold every box below them (outward rounding is monotonic)
+        Node root;
+        if (hipMemcpy(&root, d_tree_nodes, sizeof(Node), hipMemcpyDeviceToHost) != hipSuccess)
+            return bail(fail(RT_ERR_DEVICE, "rt_scene_create: download of the root node failed"));
+        take_node(root);
+    }
+    for (const Node& nd : bvh.nodes) take_node(nd);
     // f16 copy of the nodes for the LDS-resident kernel: scenes that leave room for two workgroups per CU.  The
     // values are (plane - hbase) / hstep with hbase = the centre of the box above and hstep a power of two that puts
     // the half extent in [512, 1024): f16 then resolves 2^-11 of a plane's distance from the scene's centre, whatever
@@ -1938,8 +2051,8 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
     }
     {
         const size_t n_prims = n_s + n_d;
-        const size_t scene_bytes = 32 * bvh.nodes.size() + 32 * n_s + 16 * n_prims + 2 * 16 * ((n_prims + 3) / 4);
-        if (n_s > 0 && lds16_launch_bytes(scene_bytes, sc->stack_depth) <= kLdsPerCu / 2) {
+        const size_t scene_bytes = 32 * n_nodes + 32 * n_s + 16 * n_prims + 2 * 16 * ((n_prims + 3) / 4);
+        if (n_s > 0 && !resident && lds16_launch_bytes(scene_bytes, sc->stack_depth) <= kLdsPerCu / 2) {
             std::vector<Node16> n16(bvh.nodes.size());
             auto rel = [&](float plane, int a) { return (double(plane) - double(sc->dev.hbase[a])) / double(sc->dev.hstep[a]); };  // exact
             // centre = the half float nearest to the box's middle, half extent = the smallest half float that still
@@ -1988,6 +2101,17 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
             while (q < 65535.0 && double(base[a]) + q * double(step[a]) < double(v)) q += 1.0;
             return uint16_t(q);
         };
+        if (resident) {
+            void* p = nullptr;
+            if (hipMalloc(&p, n_nodes * sizeof(Node32)) != hipSuccess) return bail(fail(RT_ERR_DEVICE, "rt_scene_create: hipMalloc of the quantised nodes failed"));
+            sc->allocations.push_back(p);
+            sc->info.device_bytes += n_nodes * sizeof(Node32);
+            hipLaunchKernelGGL(encode32_kernel, dim3(uint32_t((n_nodes + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr, d_tree_nodes,
+                               uint32_t(n_nodes), make_float3(base[0], base[1], base[2]), make_float3(step[0], step[1], step[2]),
+                               static_cast<Node32*>(p));
+            if (hipGetLastError() != hipSuccess) return bail(fail(RT_ERR_DEVICE, "rt_scene_create: launch of the node encoder failed"));
+            sc->dev.nodes32 = static_cast<const Node32*>(p);
+        }
         std::vector<Node32> n32(bvh.nodes.size());
         for (size_t i = 0; i < bvh.nodes.size(); ++i) {
             const Node& nd = bvh.nodes[i];
@@ -2001,17 +2125,51 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
             }
             n32[i].child0 = nd.child0; n32[i].child1 = nd.child1;
         }
-        if ((rc = upload(sc, n32, &sc->dev.nodes32)) != RT_OK) return bail(rc);
+        if (!resident && (rc = upload(sc, n32, &sc->dev.nodes32)) != RT_OK) return bail(rc);
     }
-    if ((rc = upload(sc, bvh.nodes, &sc->dev.nodes)) != RT_OK) return bail(rc);
-    if ((rc = upload(sc, h_sph, &sc->dev.sph)) != RT_OK) return bail(rc);
+    lap("nodes encoded");
+    if (resident) {
+        sc->dev.nodes = d_tree_nodes;
+        // the four sphere tables: uploaded in build order, put into leaf order by the device
+        auto in_leaf_order = [&](auto& host, auto** final_ptr) -> int {
+            using T = typename std::remove_reference<decltype(host)>::type::value_type;
+            const T* staged = nullptr;
+            int r = upload(sc, host, &staged);
+            if (r != RT_OK) return r;
+            void* p = nullptr;
+            RT_HIP(hipMalloc(&p, host.size() * sizeof(T)));
+            sc->allocations.push_back(p);
+            hipLaunchKernelGGL(gather_kernel<T>, dim3(uint32_t((host.size() + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr, staged,
+                               d_leaf_order, uint32_t(n_tree), uint32_t(host.size()), static_cast<T*>(p));
+            RT_HIP(hipGetLastError());
+            RT_HIP(hipDeviceSynchronize());
+            // the staged copy was the last allocation but one
+            sc->allocations.erase(sc->allocations.end() - 2);
+            (void)hipFree(const_cast<T*>(staged));
+            *final_ptr = static_cast<const T*>(p);
+            return RT_OK;
+        };
+        if ((rc = in_leaf_order(h_sph, &sc->dev.sph)) != RT_OK) return bail(rc);
+        if ((rc = in_leaf_order(h_mat, &sc->dev.mat)) != RT_OK) return bail(rc);
+        if ((rc = in_leaf_order(h_kind, &sc->dev.kind)) != RT_OK) return bail(rc);
+        if ((rc = in_leaf_order(h_id, &sc->dev.prim_id)) != RT_OK) return bail(rc);
+        // build-time buffers: the spheres in build order and the leaf order
+        for (void* p : {static_cast<void*>(d_build_sph), static_cast<void*>(d_leaf_order)}) {
+            sc->allocations.erase(std::find(sc->allocations.begin(), sc->allocations.end(), p));
+            (void)hipFree(p);
+        }
+    } else {
+        if ((rc = upload(sc, bvh.nodes, &sc->dev.nodes)) != RT_OK) return bail(rc);
+        if ((rc = upload(sc, h_sph, &sc->dev.sph)) != RT_OK) return bail(rc);
+        if ((rc = upload(sc, h_mat, &sc->dev.mat)) != RT_OK) return bail(rc);
+        if ((rc = upload(sc, h_kind, &sc->dev.kind)) != RT_OK) return bail(rc);
+        if ((rc = upload(sc, h_id, &sc->dev.prim_id)) != RT_OK) return bail(rc);
+    }
+    lap("tables on device");
     if ((rc = upload(sc, h_disc, &sc->dev.discs)) != RT_OK) return bail(rc);
-    if ((rc = upload(sc, h_mat, &sc->dev.mat)) != RT_OK) return bail(rc);
-    if ((rc = upload(sc, h_kind, &sc->dev.kind)) != RT_OK) return bail(rc);
-    if ((rc = upload(sc, h_id, &sc->dev.prim_id)) != RT_OK) return bail(rc);
     if ((rc = upload(sc, h_texmat, &sc->dev.texmat)) != RT_OK) return bail(rc);
     if ((rc = upload(sc, h_teximg, &sc->dev.teximg)) != RT_OK) return bail(rc);
-    sc->dev.n_nodes = int32_t(bvh.nodes.size());
+    sc->dev.n_nodes = int32_t(n_nodes);
     sc->dev.n_spheres = int32_t(n_s);
     sc->dev.n_tree = int32_t(n_tree);
     sc->dev.n_wide = int32_t(n_wide);
@@ -2025,7 +2183,7 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
                 for (float base : {sc->dev.hbase[a], sc->dev.qbase[a]})
                     rel = std::max(rel, std::fabs(c[a] - double(base)) + std::fabs(r));
         };
-        for (const rt_hittable& h : sc->hittables) take(h.centre, h.radius);
+        for (size_t i = 0; i < n_hittables; ++i) take(hittables[i].centre, hittables[i].radius);
         sc->bound_rel = rel;
     }
     {
@@ -2043,10 +2201,11 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
         if ((rc = resident_blocks(sc, false, sc->lds_scene, kModeProduction, &per_cu)) != RT_OK) return bail(rc);
     }
 
+    lap("rest");
     sc->info.n_hittables = n_hittables;
     sc->info.n_spheres = n_s;
     sc->info.n_discs = n_d;
-    sc->info.n_nodes = bvh.nodes.size();
+    sc->info.n_nodes = n_nodes;
     sc->info.bvh_depth = bvh.depth;
     sc->info.stack_depth = sc->stack_depth;
     sc->info.device = device;

@@ -40,6 +40,12 @@ void build_bvh(const double* spheres, size_t n, uint32_t max_depth, BuiltBvh* ou
 // for the topology, one thread per leaf for the boxes (rt_lbvh.hip).  Returns an rt_status.
 int build_lbvh_device(const double* spheres, size_t n, BuiltBvh* out);
 
+// The same build with the result left in device memory (n >= 2): *d_sph_out = the spheres as given (4 doubles each,
+// build order), *d_nodes_out = n - 1 nodes in depth-first order, *d_order_out = leaf position -> build order; the
+// caller owns the three buffers (hipFree).  scene_lo / scene_hi = box around the spheres.
+int build_lbvh_resident(const double* spheres, size_t n, double** d_sph_out, Node** d_nodes_out, uint32_t** d_order_out,
+                        uint32_t* depth_out, double scene_lo[3], double scene_hi[3]);
+
 // SplitMix64 used by the seeded scene generators.
 struct SplitMix64 {
     uint64_t state;

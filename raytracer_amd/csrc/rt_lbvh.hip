@@ -13,6 +13,9 @@
 //      flag per node) finds the other child's box already stored, so every node gets both child
 //      boxes (f32, rounded outward from the f64 boxes [c - r, c + r] of src/boundingvolume.rs:246-248)
 //      and the number of levels below it
+//   5. one thread per inner node renumbers it in depth-first order (a node's new index = first leaf of its range
+//      + the number of left turns on the way down to it), so that a node's left child is its neighbour in memory
+//      as in the host builder's trees
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -63,7 +66,8 @@ __device__ __forceinline__ int prefix(const uint32_t* __restrict__ keys, int n, 
 
 // Inner node i of n - 1 (node 0 is the root); leaves are coded ~position as in Node.
 __global__ void hierarchy_kernel(const uint32_t* __restrict__ keys, int n, Node* __restrict__ nodes,
-                                 int32_t* __restrict__ parent_of_inner, int32_t* __restrict__ parent_of_leaf) {
+                                 int32_t* __restrict__ parent_of_inner, int32_t* __restrict__ parent_of_leaf,
+                                 int32_t* __restrict__ first_leaf) {
     const int i = int(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= n - 1) return;
     const int d = (prefix(keys, n, i, i + 1) - prefix(keys, n, i, i - 1)) >= 0 ? 1 : -1;
@@ -86,6 +90,7 @@ __global__ void hierarchy_kernel(const uint32_t* __restrict__ keys, int n, Node*
     const int32_t right = (last == split + 1) ? ~(split + 1) : split + 1;
     nodes[i].child0 = left;
     nodes[i].child1 = right;
+    first_leaf[i] = first;
     if (left < 0) parent_of_leaf[~left] = i; else parent_of_inner[left] = i;
     if (right < 0) parent_of_leaf[~right] = i; else parent_of_inner[right] = i;
     if (i == 0) parent_of_inner[0] = -1;
@@ -124,6 +129,95 @@ __global__ void refit_kernel(const double4* __restrict__ sph, const uint32_t* __
     }
 }
 
+// Depth-first (preorder) index of an inner node: its first leaf + the left turns on the path from the root.
+// (Leaves before the node hang off that path in subtrees that were left behind at right turns; a subtree of m leaves
+// holds m - 1 inner nodes; the ancestors themselves come first too: first - right turns + depth = first + left turns.)
+__global__ void relabel_kernel(const Node* __restrict__ nodes, const int32_t* __restrict__ parent_of_inner,
+                               const int32_t* __restrict__ first_leaf, int n_inner, Node* __restrict__ out) {
+    const int i = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n_inner) return;
+    int left_turns = 0;
+    for (int node = i, parent = parent_of_inner[i]; parent >= 0; node = parent, parent = parent_of_inner[parent])
+        left_turns += nodes[parent].child0 == node ? 1 : 0;
+    Node nd = nodes[i];
+    if (nd.child0 >= 0) nd.child0 = first_leaf[nd.child0] + left_turns + 1;
+    if (nd.child1 >= 0) nd.child1 = first_leaf[nd.child1] + left_turns;
+    nd.pad[0] = nd.pad[1] = 0;
+    out[first_leaf[i] + left_turns] = nd;
+}
+
+}  // namespace
+
+namespace {
+
+// Steps 1-5 on spheres that are already in device memory (n >= 2).  On success *nodes_out (n - 1 nodes, depth-first
+// order) and *order_out (leaf position -> index into d_sph) are device buffers the caller frees with hipFree.
+int lbvh_on_device(const double4* d_sph, size_t n, const double clo[3], const double chi[3], Node** nodes_out, uint32_t** order_out,
+                   uint32_t* depth_out) {
+    *nodes_out = nullptr;
+    *order_out = nullptr;
+    const double3 lo = make_double3(clo[0], clo[1], clo[2]);
+    auto inv = [](double e) { return e > 0.0 ? 1.0 / e : 0.0; };
+    const double3 inv_extent = make_double3(inv(chi[0] - clo[0]), inv(chi[1] - clo[1]), inv(chi[2] - clo[2]));
+    int rc = RT_OK;
+    const int ni = int(n);
+    uint32_t *d_keys = nullptr, *d_keys2 = nullptr, *d_vals = nullptr, *d_vals2 = nullptr, *d_arrived = nullptr;
+    int32_t *d_pin = nullptr, *d_pleaf = nullptr, *d_first = nullptr;
+    Node *d_nodes = nullptr, *d_nodes_dfs = nullptr;
+    void* d_tmp = nullptr;
+    size_t tmp_bytes = 0;
+    const uint32_t block = 256, grid_n = uint32_t((n + block - 1) / block), grid_i = uint32_t((n - 1 + block - 1) / block);
+    {
+        LBVH_HIP(hipMalloc(&d_keys, n * 4)); LBVH_HIP(hipMalloc(&d_keys2, n * 4));
+        LBVH_HIP(hipMalloc(&d_vals, n * 4)); LBVH_HIP(hipMalloc(&d_vals2, n * 4));
+        LBVH_HIP(hipMalloc(&d_pin, n * 4)); LBVH_HIP(hipMalloc(&d_pleaf, n * 4));
+        LBVH_HIP(hipMalloc(&d_arrived, n * 4));
+        LBVH_HIP(hipMalloc(&d_nodes, (n - 1) * sizeof(Node)));
+        LBVH_HIP(hipMalloc(&d_nodes_dfs, (n - 1) * sizeof(Node)));
+        LBVH_HIP(hipMalloc(&d_first, n * 4));
+        LBVH_HIP(hipMemsetAsync(d_arrived, 0, n * 4, nullptr));
+        LBVH_HIP(hipMemsetAsync(d_nodes, 0, (n - 1) * sizeof(Node), nullptr));
+        hipLaunchKernelGGL(morton_kernel, dim3(grid_n), dim3(block), 0, nullptr, d_sph, uint32_t(n), lo, inv_extent, d_keys, d_vals);
+        LBVH_HIP(hipGetLastError());
+        LBVH_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys, d_keys2, d_vals, d_vals2, ni, 0, 30, nullptr));
+        LBVH_HIP(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
+        LBVH_HIP(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_keys, d_keys2, d_vals, d_vals2, ni, 0, 30, nullptr));
+        hipLaunchKernelGGL(hierarchy_kernel, dim3(grid_i), dim3(block), 0, nullptr, d_keys2, ni, d_nodes, d_pin, d_pleaf, d_first);
+        LBVH_HIP(hipGetLastError());
+        hipLaunchKernelGGL(refit_kernel, dim3(grid_n), dim3(block), 0, nullptr, d_sph, d_vals2, ni, d_nodes, d_pin, d_pleaf, d_arrived);
+        LBVH_HIP(hipGetLastError());
+        {
+            Node root;  // pad[] of the root = levels below its children; the renumbering clears the pads
+            LBVH_HIP(hipMemcpy(&root, d_nodes, sizeof(Node), hipMemcpyDeviceToHost));
+            *depth_out = uint32_t(1 + std::max(root.pad[0], root.pad[1]));
+        }
+        hipLaunchKernelGGL(relabel_kernel, dim3(grid_i), dim3(block), 0, nullptr, d_nodes, d_pin, d_first, ni - 1, d_nodes_dfs);
+        LBVH_HIP(hipGetLastError());
+        LBVH_HIP(hipDeviceSynchronize());
+        *nodes_out = d_nodes_dfs; d_nodes_dfs = nullptr;
+        *order_out = d_vals2; d_vals2 = nullptr;
+    }
+done:
+    for (void* p : {static_cast<void*>(d_keys), static_cast<void*>(d_keys2), static_cast<void*>(d_vals),
+                    static_cast<void*>(d_vals2), static_cast<void*>(d_pin), static_cast<void*>(d_pleaf),
+                    static_cast<void*>(d_arrived), static_cast<void*>(d_nodes), static_cast<void*>(d_nodes_dfs),
+                    static_cast<void*>(d_first), d_tmp})
+        (void)hipFree(p);
+    return rc;
+}
+
+// boxes around the centres (the Morton grid) and around the spheres
+void sphere_extents(const double* spheres, size_t n, double clo[3], double chi[3], double slo[3], double shi[3]) {
+    for (int a = 0; a < 3; ++a) { clo[a] = slo[a] = 1e300; chi[a] = shi[a] = -1e300; }
+    for (size_t i = 0; i < n; ++i) {
+        const double* s = spheres + 4 * i;
+        for (int a = 0; a < 3; ++a) {
+            clo[a] = std::min(clo[a], s[a]); chi[a] = std::max(chi[a], s[a]);
+            slo[a] = std::min(slo[a], s[a] - std::fabs(s[3])); shi[a] = std::max(shi[a], s[a] + std::fabs(s[3]));
+        }
+    }
+}
+
 }  // namespace
 
 // Same contract as build_bvh (rt_internal.h); runs on the current HIP device, synchronous.
@@ -137,60 +231,47 @@ int build_lbvh_device(const double* spheres, size_t n, BuiltBvh* out) {
         return RT_OK;
     }
     if (n > (size_t(1) << 30)) return fail(RT_ERR_LIMIT, "build_lbvh_device: more than 2^30 spheres");
-    double clo[3] = {1e300, 1e300, 1e300}, chi[3] = {-1e300, -1e300, -1e300};
-    double slo[3] = {1e300, 1e300, 1e300}, shi[3] = {-1e300, -1e300, -1e300};
-    for (size_t i = 0; i < n; ++i) {
-        const double* s = spheres + 4 * i;
-        for (int a = 0; a < 3; ++a) {
-            clo[a] = std::min(clo[a], s[a]); chi[a] = std::max(chi[a], s[a]);
-            slo[a] = std::min(slo[a], s[a] - std::fabs(s[3])); shi[a] = std::max(shi[a], s[a] + std::fabs(s[3]));
-        }
-    }
-    for (int a = 0; a < 3; ++a) { out->scene_lo[a] = slo[a]; out->scene_hi[a] = shi[a]; }
-    const double3 lo = make_double3(clo[0], clo[1], clo[2]);
-    auto inv = [](double e) { return e > 0.0 ? 1.0 / e : 0.0; };
-    const double3 inv_extent = make_double3(inv(chi[0] - clo[0]), inv(chi[1] - clo[1]), inv(chi[2] - clo[2]));
-
+    double clo[3], chi[3];
+    sphere_extents(spheres, n, clo, chi, out->scene_lo, out->scene_hi);
     int rc = RT_OK;
-    const int ni = int(n);
     double4* d_sph = nullptr;
-    uint32_t *d_keys = nullptr, *d_keys2 = nullptr, *d_vals = nullptr, *d_vals2 = nullptr, *d_arrived = nullptr;
-    int32_t *d_pin = nullptr, *d_pleaf = nullptr;
     Node* d_nodes = nullptr;
-    void* d_tmp = nullptr;
-    size_t tmp_bytes = 0;
-    const uint32_t block = 256, grid_n = uint32_t((n + block - 1) / block), grid_i = uint32_t((n - 1 + block - 1) / block);
+    uint32_t* d_order = nullptr;
     {
         LBVH_HIP(hipMalloc(&d_sph, n * sizeof(double4)));
-        LBVH_HIP(hipMalloc(&d_keys, n * 4)); LBVH_HIP(hipMalloc(&d_keys2, n * 4));
-        LBVH_HIP(hipMalloc(&d_vals, n * 4)); LBVH_HIP(hipMalloc(&d_vals2, n * 4));
-        LBVH_HIP(hipMalloc(&d_pin, n * 4)); LBVH_HIP(hipMalloc(&d_pleaf, n * 4));
-        LBVH_HIP(hipMalloc(&d_arrived, n * 4));
-        LBVH_HIP(hipMalloc(&d_nodes, (n - 1) * sizeof(Node)));
         LBVH_HIP(hipMemcpy(d_sph, spheres, n * sizeof(double4), hipMemcpyHostToDevice));
-        LBVH_HIP(hipMemsetAsync(d_arrived, 0, n * 4, nullptr));
-        LBVH_HIP(hipMemsetAsync(d_nodes, 0, (n - 1) * sizeof(Node), nullptr));
-        hipLaunchKernelGGL(morton_kernel, dim3(grid_n), dim3(block), 0, nullptr, d_sph, uint32_t(n), lo, inv_extent, d_keys, d_vals);
-        LBVH_HIP(hipGetLastError());
-        LBVH_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys, d_keys2, d_vals, d_vals2, ni, 0, 30, nullptr));
-        LBVH_HIP(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
-        LBVH_HIP(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_keys, d_keys2, d_vals, d_vals2, ni, 0, 30, nullptr));
-        hipLaunchKernelGGL(hierarchy_kernel, dim3(grid_i), dim3(block), 0, nullptr, d_keys2, ni, d_nodes, d_pin, d_pleaf);
-        LBVH_HIP(hipGetLastError());
-        hipLaunchKernelGGL(refit_kernel, dim3(grid_n), dim3(block), 0, nullptr, d_sph, d_vals2, ni, d_nodes, d_pin, d_pleaf, d_arrived);
-        LBVH_HIP(hipGetLastError());
+        if ((rc = lbvh_on_device(d_sph, n, clo, chi, &d_nodes, &d_order, &out->depth)) != RT_OK) goto done;
         out->nodes.resize(n - 1);
         out->leaf_order.resize(n);
         LBVH_HIP(hipMemcpy(out->nodes.data(), d_nodes, (n - 1) * sizeof(Node), hipMemcpyDeviceToHost));
-        LBVH_HIP(hipMemcpy(out->leaf_order.data(), d_vals2, n * 4, hipMemcpyDeviceToHost));
-        out->depth = uint32_t(1 + std::max(out->nodes[0].pad[0], out->nodes[0].pad[1]));
-        for (Node& nd : out->nodes) nd.pad[0] = nd.pad[1] = 0;
+        LBVH_HIP(hipMemcpy(out->leaf_order.data(), d_order, n * 4, hipMemcpyDeviceToHost));
     }
 done:
-    for (void* p : {static_cast<void*>(d_sph), static_cast<void*>(d_keys), static_cast<void*>(d_keys2), static_cast<void*>(d_vals),
-                    static_cast<void*>(d_vals2), static_cast<void*>(d_pin), static_cast<void*>(d_pleaf),
-                    static_cast<void*>(d_arrived), static_cast<void*>(d_nodes), d_tmp})
-        (void)hipFree(p);
+    (void)hipFree(d_sph);
+    (void)hipFree(d_nodes);
+    (void)hipFree(d_order);
+    return rc;
+}
+
+// The tree stays on the device: *d_sph_out (the spheres as uploaded, build order), *d_nodes_out (depth-first order),
+// *d_order_out (leaf position -> build order) belong to the caller (hipFree).  n >= 2.
+int build_lbvh_resident(const double* spheres, size_t n, double** d_sph_out, Node** d_nodes_out, uint32_t** d_order_out,
+                        uint32_t* depth_out, double scene_lo[3], double scene_hi[3]) {
+    *d_sph_out = nullptr; *d_nodes_out = nullptr; *d_order_out = nullptr;
+    if (n < 2 || n > (size_t(1) << 30)) return fail(RT_ERR_LIMIT, "build_lbvh_resident: %zu spheres", n);
+    double clo[3], chi[3];
+    sphere_extents(spheres, n, clo, chi, scene_lo, scene_hi);
+    int rc = RT_OK;
+    double4* d_sph = nullptr;
+    {
+        LBVH_HIP(hipMalloc(&d_sph, n * sizeof(double4)));
+        LBVH_HIP(hipMemcpy(d_sph, spheres, n * sizeof(double4), hipMemcpyHostToDevice));
+        if ((rc = lbvh_on_device(d_sph, n, clo, chi, d_nodes_out, d_order_out, depth_out)) != RT_OK) goto done;
+        *d_sph_out = reinterpret_cast<double*>(d_sph);
+        d_sph = nullptr;
+    }
+done:
+    (void)hipFree(d_sph);
     return rc;
 }
 

@@ -668,6 +668,25 @@ def test_lbvh_builder_million_spheres(rt):
     assert np.array_equal(ra, rb)
 
 
+def test_lbvh_tree_that_stays_on_the_device(rt, ob):
+    """From 4096 spheres up the GPU-built tree never visits the host: nodes renumbered depth-first, quantised copy and
+    sphere tables made by device kernels.  Hits against the oracle's scan over all spheres, image against the host-built tree's."""
+    from raytracer_amd import _abi
+    h = rt.gen_scene_grid(3, 70)  # 4 901 spheres
+    lb, sah = rt.Scene(h, builder="lbvh"), rt.Scene(h)
+    assert lb.info["n_nodes"] == len(h) - 2 and lb.info["n_wide"] == 1 and lb.info["lds_resident"] == 0
+    cam = rt.Camera.build([0, 0, 0], [20, 6, 5], 1.0, 0.1, 192, 108)
+    o, d = lb.generate_primary(cam, 0, 0, 192 * 108)
+    ids, t, nrm = lb.trace_primary(o, d)
+    want_ids, want_t, want_n, _ = ob.Scene(h).trace(o, d, ob.TRAVERSE_GATED_BRUTE)
+    assert (want_ids > 0).sum() > 2000
+    _check_hits(ids, t, nrm, want_ids, want_t, want_n)
+    for flags in (0, _abi.RT_RENDER_KERNEL_LOCKSTEP):  # Node32 made on the device / the f32 nodes as renumbered
+        a, _ = lb.render(cam, 4, depth=50, seed=2, want_rgb8=False, flags=flags)
+        b, _ = sah.render(cam, 4, depth=50, seed=2, want_rgb8=False, flags=flags)
+        assert np.array_equal(a, b)
+
+
 def test_render_kernel_keeps_its_occupancy(rt, scene1):
     # one register too many (129 instead of 128) once cut a quarter of the resident waves and cost 40 % of the speed
     import ctypes as C
