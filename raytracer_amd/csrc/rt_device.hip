@@ -155,6 +155,22 @@ __device__ __forceinline__ void unit_sphere(float u0, float u1, float* x, float*
 
 // ------------------------------------------------------ f64 shape tests
 // src/geometry.rs:104-121 in the reference's operation order.
+// Correctly rounded f64 square root of a discriminant: the compiler's own sequence (v_rsq_f64, one joint refinement of
+// root and half reciprocal root, two corrections of the root) without the rescaling it wraps around it for arguments
+// below 2^-767, which a discriminant of coordinates of ordinary size never is unless it is zero.  Same bits as sqrt()
+// from 2^-767 up; zero and +infinity are returned as they are; a negative argument gives NaN.
+__device__ __forceinline__ double sqrt_discriminant(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+    g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+    return __builtin_amdgcn_class(x, 0x260) ? x : g;  // +0, -0, +infinity
+}
+
 __device__ __forceinline__ bool sphere_intersect_f64(double cx, double cy, double cz, double r, double ox, double oy,
                                                      double oz, double dx, double dy, double dz, double* t) {
 #pragma clang fp contract(off)
@@ -163,7 +179,7 @@ __device__ __forceinline__ bool sphere_intersect_f64(double cx, double cy, doubl
     double c = (rx * rx + ry * ry + rz * rz) - r * r;
     double discrm = b * b - 4.0 * c;
     if (discrm < 0.0) return false;
-    double sq = __dsqrt_rn(discrm);
+    double sq = sqrt_discriminant(discrm);
     double t_smaller = -0.5 * (b + sq);
     if (t_smaller > 0.0) { *t = t_smaller; return true; }
     double t_larger = t_smaller + sq;
@@ -765,7 +781,7 @@ __device__ __forceinline__ bool sphere_candidate(const double4 s, int32_t k, int
         const double b = 2.0 * (rx * p.dx + ry * p.dy + rz * p.dz);
         const double c = (rx * rx + ry * ry + rz * rz) - s.w * s.w;
         const double discrm = b * b - 4.0 * c;
-        const double sq = __dsqrt_rn(discrm);
+        const double sq = sqrt_discriminant(discrm);
         const double t_smaller = -0.5 * (b + sq);
         const double t_larger = t_smaller + sq;
         // `&` and `|` on purpose: every comparison is evaluated, the wave takes no branch
