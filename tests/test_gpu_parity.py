@@ -252,6 +252,30 @@ def test_all_render_schedules_give_the_same_image(scene1, rt):
     assert np.allclose(a, ordered_sum(6), rtol=2e-6, atol=1e-6)  # the chunking only reorders an f32 sum
 
 
+def test_work_hand_out_covers_every_pixel_sample_once(scene1, rt):
+    """Eight work counters, tiles that hang over the frame's edge, frames smaller than a tile, waves that find their
+    counter dry and move on, bands (tree in HBM) and interleaved items (scene in LDS): whatever the frame, the image is
+    the chunk-ordered sum of the per-path colours, so every (pixel, sample) was rendered exactly once."""
+    grid = rt.Scene(rt.gen_scene_grid(2, 48))  # tree in HBM: chunks of two samples, one band of the frame per counter
+    assert grid.info["lds_resident"] == 0 and scene1.info["lds_resident"] == 1
+    for scene in (scene1, grid):
+        for (w, h, spp) in ((1, 1, 3), (7, 3, 5), (9, 17, 2), (64, 8, 1), (33, 41, 7), (8, 8, 64)):
+            cam = rt.default_camera(w, h)
+            img, _ = scene.render(cam, spp, depth=8, seed=11, want_rgb8=False)
+            px = np.repeat(np.arange(w * h, dtype=np.uint32), spp)
+            sm = np.tile(np.arange(spp, dtype=np.uint32), w * h)
+            cols = scene.trace_paths(cam, px, sm, depth=8, seed=11).reshape(w * h, spp, 3)
+            chunk = scene.render_chunk(cam, spp)
+            total = np.zeros((w * h, 3), dtype=np.float32)
+            for c0 in range(0, spp, chunk):
+                part = np.zeros((w * h, 3), dtype=np.float32)
+                for k in range(c0, min(c0 + chunk, spp)):
+                    part += cols[:, k, :]
+                total += part
+            assert np.array_equal(total.reshape(h, w, 3), img), (w, h, spp, chunk)
+    assert grid.render_chunk(rt.default_camera(64, 64), 64) == 2 and grid.render_chunk(rt.default_camera(64, 64), 1000) == 16
+
+
 def test_finalize_matches_color_to_ppm(scene1, ob, rt):
     cam = rt.default_camera(64, 64)
     s, q = scene1.render(cam, 4, depth=10, seed=1)

@@ -7,6 +7,7 @@
 //   2  without the push / pop bookkeeping
 //   3  without the scalar mask logic: the child is chosen by one v_cmp + v_cndmask
 //   4  the three compares first and the scalar logic spread between the vector instructions that follow
+//   5  the two halves of a node side by side (one address computation, second read at offset 16) instead of in two arrays
 //   hipcc --offload-arch=gfx950 -O2 -o inner_step inner_step.hip && ./inner_step
 #include <hip/hip_runtime.h>
 
@@ -79,6 +80,12 @@ constexpr int kSteps = 4096;
     "ds_read_b128 v[120:123], v112\n\t"                                                             \
     "ds_read_b128 v[124:127], v113\n\t"
 
+#define FETCH_SIDE_BY_SIDE                                                                        \
+    "s_mov_b64 exec, s[88:89]\n\t"                                                                  \
+    "v_lshl_add_u32 v112, %[node], 5, %[q0]\n\t"                                                    \
+    "ds_read_b128 v[120:123], v112\n\t"                                                             \
+    "ds_read_b128 v[124:127], v112 offset:16\n\t"
+
 #define PUSH_POP                                                                                  \
     "s_mov_b64 exec, s[96:97]\n\t"                                                                  \
     "ds_write_b32 %[sp], %[top]\n\t"                                                                \
@@ -117,7 +124,11 @@ constexpr int kSteps = 4096;
 template <int VARIANT>
 __global__ void k_inner(unsigned long long* out, const uint4* tree, float seed) {
     extern __shared__ uint4 lds[];
-    for (int i = threadIdx.x; i < 2 * kNodes; i += blockDim.x) lds[i] = tree[i];
+    if (VARIANT == 5) {
+        for (int i = threadIdx.x; i < kNodes; i += blockDim.x) { lds[2 * i] = tree[i]; lds[2 * i + 1] = tree[kNodes + i]; }
+    } else {
+        for (int i = threadIdx.x; i < 2 * kNodes; i += blockDim.x) lds[i] = tree[i];
+    }
     __syncthreads();
     const uint32_t q0 = 0, q1 = kNodes * 16;
     const uint32_t stride = blockDim.x * 4;
@@ -132,6 +143,9 @@ __global__ void k_inner(unsigned long long* out, const uint4* tree, float seed) 
     if (VARIANT == 2) asm volatile(HEAD SLAB SELECT_SCALAR EXIT_TEST FETCH COUNT OPERANDS);
     if (VARIANT == 3) asm volatile(HEAD SLAB SELECT_VECTOR EXIT_TEST FETCH PUSH_POP COUNT OPERANDS);
     if (VARIANT == 4) asm volatile(HEAD SLAB SELECT_SPREAD EXIT_TEST FETCH PUSH_POP COUNT OPERANDS);
+    if (VARIANT == 5)
+        asm volatile("s_mov_b64 s[88:89], exec\n\ts_mov_b32 s86, %[n]\n\t" FETCH_SIDE_BY_SIDE "1:\n\ts_waitcnt lgkmcnt(0)\n\t" SLAB SELECT_SCALAR EXIT_TEST
+                         FETCH_SIDE_BY_SIDE PUSH_POP COUNT OPERANDS);
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if (node == 0x12345678 && sp == 7u && top == 3) out[1] = 1;
     if ((threadIdx.x & 63) == 0) atomicAdd(out, t1 - t0);
@@ -166,9 +180,9 @@ int main() {
     CHECK(hipMalloc(&d_tree, tree.size() * 4));
     CHECK(hipMemcpy(d_tree, tree.data(), tree.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMalloc(&d_out, 16));
-    const char* names[5] = {"loop as run", "no exit test", "no push/pop", "vector select", "scalar logic spread"};
+    const char* names[6] = {"loop as run", "no exit test", "no push/pop", "vector select", "scalar logic spread", "node halves side by side"};
     std::printf("%-22s %14s %14s %14s   (SIMD cycles per step of one wave, 64 lanes on)\n", "variant", "1 wave/SIMD", "2 waves/SIMD", "4 waves/SIMD");
-    for (int v = 0; v < 5; ++v) {
+    for (int v = 0; v < 6; ++v) {
         double cyc[3];
         int slot = 0;
         for (int threads : {256, 512, 1024}) {
@@ -179,7 +193,8 @@ int main() {
                 case 1: hipLaunchKernelGGL(k_inner<1>, dim3(n_cu), dim3(threads), lds_bytes, 0, d_out, d_tree, 1.5f); break;
                 case 2: hipLaunchKernelGGL(k_inner<2>, dim3(n_cu), dim3(threads), lds_bytes, 0, d_out, d_tree, 1.5f); break;
                 case 3: hipLaunchKernelGGL(k_inner<3>, dim3(n_cu), dim3(threads), lds_bytes, 0, d_out, d_tree, 1.5f); break;
-                default: hipLaunchKernelGGL(k_inner<4>, dim3(n_cu), dim3(threads), lds_bytes, 0, d_out, d_tree, 1.5f); break;
+                case 4: hipLaunchKernelGGL(k_inner<4>, dim3(n_cu), dim3(threads), lds_bytes, 0, d_out, d_tree, 1.5f); break;
+                default: hipLaunchKernelGGL(k_inner<5>, dim3(n_cu), dim3(threads), lds_bytes, 0, d_out, d_tree, 1.5f); break;
             }
             CHECK(hipDeviceSynchronize());
             unsigned long long hh[2];
