@@ -2117,7 +2117,14 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
             while (q < 65535.0 && double(base[a]) + q * double(step[a]) < double(v)) q += 1.0;
             return uint16_t(q);
         };
-        if (resident) {
+        // large trees are quantised by the device kernel whichever builder made them (the host loop below takes
+        // 40 ms per million nodes); the f32 nodes are on the device already or go there now
+        const bool encode_on_device = resident || n_nodes >= kResidentMin;
+        if (encode_on_device && !resident) {
+            if ((rc = upload(sc, bvh.nodes, &sc->dev.nodes)) != RT_OK) return bail(rc);
+            d_tree_nodes = const_cast<Node*>(sc->dev.nodes);
+        }
+        if (encode_on_device) {
             void* p = nullptr;
             if (hipMalloc(&p, n_nodes * sizeof(Node32)) != hipSuccess) return bail(fail(RT_ERR_DEVICE, "rt_scene_create: hipMalloc of the quantised nodes failed"));
             sc->allocations.push_back(p);
@@ -2125,11 +2132,12 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
             hipLaunchKernelGGL(encode32_kernel, dim3(uint32_t((n_nodes + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr, d_tree_nodes,
                                uint32_t(n_nodes), make_float3(base[0], base[1], base[2]), make_float3(step[0], step[1], step[2]),
                                static_cast<Node32*>(p));
-            if (hipGetLastError() != hipSuccess) return bail(fail(RT_ERR_DEVICE, "rt_scene_create: launch of the node encoder failed"));
+            if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+                return bail(fail(RT_ERR_DEVICE, "rt_scene_create: the node encoder failed"));
             sc->dev.nodes32 = static_cast<const Node32*>(p);
         }
-        std::vector<Node32> n32(bvh.nodes.size());
-        for (size_t i = 0; i < bvh.nodes.size(); ++i) {
+        std::vector<Node32> n32(encode_on_device ? 0 : bvh.nodes.size());
+        for (size_t i = 0; i < n32.size(); ++i) {
             const Node& nd = bvh.nodes[i];
             for (int a = 0; a < 3; ++a) {
                 // grid bounds (rounded outward), then centre and half extent in grid units: the centre is a grid
@@ -2141,7 +2149,7 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
             }
             n32[i].child0 = nd.child0; n32[i].child1 = nd.child1;
         }
-        if (!resident && (rc = upload(sc, n32, &sc->dev.nodes32)) != RT_OK) return bail(rc);
+        if (!encode_on_device && (rc = upload(sc, n32, &sc->dev.nodes32)) != RT_OK) return bail(rc);
     }
     lap("nodes encoded");
     if (resident) {
@@ -2175,7 +2183,7 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
             (void)hipFree(p);
         }
     } else {
-        if ((rc = upload(sc, bvh.nodes, &sc->dev.nodes)) != RT_OK) return bail(rc);
+        if (!sc->dev.nodes && (rc = upload(sc, bvh.nodes, &sc->dev.nodes)) != RT_OK) return bail(rc);
         if ((rc = upload(sc, h_sph, &sc->dev.sph)) != RT_OK) return bail(rc);
         if ((rc = upload(sc, h_mat, &sc->dev.mat)) != RT_OK) return bail(rc);
         if ((rc = upload(sc, h_kind, &sc->dev.kind)) != RT_OK) return bail(rc);
