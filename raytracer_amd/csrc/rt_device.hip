@@ -1518,6 +1518,9 @@ struct rt_scene {
     std::vector<void*> allocations;
     uint32_t* d_work_counter = nullptr;
     float* d_partials = nullptr;        // partial-sum slots of chunked renders, grown on demand
+    float* d_frame_sum = nullptr;       // frame buffers of rt_render (host-buffer entry point), kept between calls
+    uint8_t* d_frame_rgb = nullptr;
+    size_t frame_pixels = 0;
     size_t partials_bytes = 0;
     const Node16* d_nodes16 = nullptr;  // f16 copy of the nodes for the LDS-resident kernel (null when it has none)
     bool lds_scene = false;             // the render kernel stages nodes and primitive tables in LDS
@@ -1786,6 +1789,8 @@ void rt_scene_destroy(rt_scene* scene) {
     (void)hipSetDevice(scene->device);
     if (scene->ev_done) { (void)hipEventSynchronize(scene->ev_done); (void)hipEventDestroy(scene->ev_done); }
     if (scene->d_partials) (void)hipFree(scene->d_partials);
+    if (scene->d_frame_sum) (void)hipFree(scene->d_frame_sum);
+    if (scene->d_frame_rgb) (void)hipFree(scene->d_frame_rgb);
     for (void* p : scene->allocations) (void)hipFree(p);
     delete scene;
 }
@@ -2452,22 +2457,25 @@ int rt_finalize_device(const rt_scene* scene, const float* d_sum_rgb, size_t n_p
 int rt_render(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, float* sum_rgb, uint8_t* rgb8) {
     int rc = check_render_args(scene, cam, opts, "rt_render");
     if (rc != RT_OK) return rc;
+    if ((opts->flags & RT_RENDER_ACCUMULATE) && !sum_rgb) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: RT_RENDER_ACCUMULATE needs sum_rgb");
     DeviceGuard guard;
     RT_HIP(hipSetDevice(scene->device));
     const size_t n_pixels = size_t(cam->horiz_res) * cam->vert_res;
-    float* d_sum = nullptr;
-    uint8_t* d_rgb = nullptr;
-    RT_HIP(hipMalloc(reinterpret_cast<void**>(&d_sum), n_pixels * 3 * sizeof(float)));
-    auto cleanup = [&]() { (void)hipFree(d_sum); if (d_rgb) (void)hipFree(d_rgb); };
-    if ((opts->flags & RT_RENDER_ACCUMULATE) && sum_rgb) {
-        if (hipMemcpy(d_sum, sum_rgb, n_pixels * 3 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return fail(RT_ERR_DEVICE, "rt_render: upload of the running sum failed"); }
-    } else if (opts->flags & RT_RENDER_ACCUMULATE) {
-        cleanup();
-        return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: RT_RENDER_ACCUMULATE needs sum_rgb");
+    if (n_pixels > scene->frame_pixels) {  // the handle keeps its frame buffers: a second call of the same size allocates nothing
+        RT_HIP(hipEventSynchronize(scene->ev_done));
+        if (scene->d_frame_sum) (void)hipFree(scene->d_frame_sum);
+        if (scene->d_frame_rgb) (void)hipFree(scene->d_frame_rgb);
+        scene->d_frame_sum = nullptr; scene->d_frame_rgb = nullptr; scene->frame_pixels = 0;
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_frame_sum), n_pixels * 3 * sizeof(float)));
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_frame_rgb), n_pixels * 3));
+        scene->frame_pixels = n_pixels;
     }
+    float* d_sum = scene->d_frame_sum;
+    uint8_t* d_rgb = scene->d_frame_rgb;
+    if (opts->flags & RT_RENDER_ACCUMULATE)
+        if (hipMemcpy(d_sum, sum_rgb, n_pixels * 3 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail(RT_ERR_DEVICE, "rt_render: upload of the running sum failed");
     rc = rt_render_device(scene, cam, opts, d_sum, nullptr);
     if (rc == RT_OK && rgb8) {
-        if (hipMalloc(reinterpret_cast<void**>(&d_rgb), n_pixels * 3) != hipSuccess) { cleanup(); return fail(RT_ERR_DEVICE, "rt_render: hipMalloc failed"); }
         // a running sum handed in with RT_RENDER_ACCUMULATE is taken to hold samples [0, sample_begin)
         const uint32_t in_sum = (opts->flags & RT_RENDER_ACCUMULATE) ? opts->sample_end : opts->sample_end - opts->sample_begin;
         rc = rt_finalize_device(scene, d_sum, n_pixels, in_sum, d_rgb, nullptr);
@@ -2475,7 +2483,6 @@ int rt_render(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts,
     if (rc == RT_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(RT_ERR_DEVICE, "rt_render: kernel execution failed: %s", hipGetErrorString(hipGetLastError()));
     if (rc == RT_OK && sum_rgb && hipMemcpy(sum_rgb, d_sum, n_pixels * 3 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(RT_ERR_DEVICE, "rt_render: download failed");
     if (rc == RT_OK && rgb8 && hipMemcpy(rgb8, d_rgb, n_pixels * 3, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(RT_ERR_DEVICE, "rt_render: download failed");
-    cleanup();
     return rc;
 }
 
