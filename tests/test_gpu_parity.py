@@ -4,6 +4,8 @@ Bars: primitive IDs bit-exact; hit parameter and normal within 1e-5 relative (th
 f64 rounding level because the device runs the reference's f64 sphere test); per-path colours
 within 2e-4 except the few paths where an f32 rounding flips a discrete decision; images by PSNR.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -783,6 +785,33 @@ def test_render_multi_splits_samples_over_scene_handles(rt, scene1):
     assert np.array_equal(one, whole) and np.array_equal(q_one, q_whole)
     with pytest.raises(rt.RtError):
         rt.render_multi(scenes, cam, 2)  # fewer samples than devices
+
+
+def test_render_multi_reduces_through_rccl(rt):
+    """The RCCL branch of rt_render_multi with the one communicator a one-GPU box allows (RT_MULTI_REDUCE=rccl, one
+    handle): librccl is found and bound, ncclCommInitAll / ncclReduce run on the render's stream, and the image that
+    comes back is the plain render's.  In a process of its own: RCCL keeps threads and device memory until exit."""
+    import subprocess
+    import sys
+
+    code = (
+        "import os, sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import raytracer_amd as rt\n"
+        "sc = rt.Scene(rt.gen_scene(1)); cam = rt.default_camera(160, 96)\n"
+        "whole, q = sc.render(cam, 10, depth=50, seed=4)\n"
+        "os.environ['RT_MULTI_REDUCE'] = 'rccl'\n"
+        "try:\n"
+        "    one, q1 = rt.render_multi([sc], cam, 10, depth=50, seed=4)\n"
+        "except rt.RtError as e:\n"
+        "    print('NO-RCCL' if 'could not be loaded' in str(e) else 'ERROR', e); sys.exit(0)\n"
+        "print('EQUAL' if np.array_equal(one, whole) and np.array_equal(q1, q) else 'DIFFERENT')\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=150)
+    assert out.returncode == 0, out.stderr[-2000:]
+    if "NO-RCCL" in out.stdout:
+        pytest.skip("librccl.so is not loadable on this machine")
+    assert "EQUAL" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
 def test_render_device_only_enqueues_once_reserved(rt, scene1):
