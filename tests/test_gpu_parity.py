@@ -713,6 +713,44 @@ def test_lbvh_tree_that_stays_on_the_device(rt, ob):
         assert np.array_equal(a, b)
 
 
+def test_random_scenes_across_size_thresholds(rt, ob):
+    """Random scenes of any scale and position (a tenth of the radii negative, sometimes a giant sphere underneath)
+    on both sides of every rule that depends on the sphere count: no tree (12 / 13), scene in LDS or not, tree kept
+    on the device (4095 / 4096).  Both builders: nearest hits against the oracle's scan over all spheres, and the
+    render kernel's image against the ordered sum of the per-path entry point's colours."""
+    rng = np.random.default_rng(7)
+    for n in (1, 2, 12, 13, 300, 1500, 4095, 4096, 6000):
+        for giant in (False, True):
+            scale = 10.0 ** rng.uniform(-2, 3)
+            shift = rng.normal(0, 1, 3) * scale * 10.0 ** rng.uniform(-1, 2)
+            items = [rt.sphere(list(rng.uniform(-1, 1, 3) * scale + shift), float(scale * 10.0 ** rng.uniform(-3, -0.5) * (1 if rng.random() > 0.1 else -1)),
+                               rt.diffuse([.5, .5, .5])) for _ in range(n)]
+            if giant and n > 1:
+                items[0] = rt.sphere([float(shift[0]), float(shift[1] - 1001 * scale), float(shift[2])], 1000.0 * scale, rt.diffuse([.5, .5, .5]))
+            h = rt.hittables(items)
+            m = 2000
+            o = (rng.uniform(-2, 2, (m, 3)) * scale + shift).astype(np.float32)
+            aim = h["centre"][rng.integers(0, n, m)] + rng.normal(0, 0.3, (m, 3)) * np.abs(h["radius"][rng.integers(0, n, m)])[:, None]
+            d = aim - o
+            d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+            want_ids, want_t, want_n, _ = ob.Scene(h).trace(o, d, ob.TRAVERSE_GATED_BRUTE)
+            cam = rt.Camera.build([float(x) for x in shift], [float(x) for x in (shift + np.array([2.5, 1.0, 2.0]) * scale)], 1.0, 0.05 * scale, 40, 24)
+            px = np.repeat(np.arange(40 * 24, dtype=np.uint32), 3)
+            sm = np.tile(np.arange(3, dtype=np.uint32), 40 * 24)
+            for builder in ("sah", "lbvh"):
+                sc = rt.Scene(h, builder=builder)
+                ids, t, nrm = sc.trace_primary(o, d)
+                assert np.array_equal(ids, want_ids), (n, giant, builder)
+                hit = want_ids >= 0
+                assert np.allclose(t[hit], want_t[hit], rtol=1e-9, atol=0), (n, giant, builder)
+                img, _ = sc.render(cam, 3, depth=6, seed=1, want_rgb8=False, samples_per_item=3)
+                cols = sc.trace_paths(cam, px, sm, depth=6, seed=1).reshape(40 * 24, 3, 3)
+                total = np.zeros((40 * 24, 3), dtype=np.float32)
+                for k in range(3):
+                    total += cols[:, k, :]
+                assert np.array_equal(total.reshape(24, 40, 3), img), (n, giant, builder)
+
+
 def test_render_kernel_keeps_its_occupancy(rt, scene1):
     # one register too many (129 instead of 128) once cut a quarter of the resident waves and cost 40 % of the speed
     import ctypes as C
