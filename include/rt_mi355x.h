@@ -276,6 +276,10 @@ int rt_trace_path_segments(rt_scene* scene, const rt_camera* cam, const rt_rende
 /* src/main.rs:35-42 + src/lib.rs:151: "P3\nW H\n255\n" then one "r g b\n" line
  * per pixel.  Unlike the reference the file is truncated first. */
 int rt_write_ppm(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height);
+/* The same image as a binary PPM: "P6\nW H\n255\n" (the header of src/main.rs:41-42 with the binary magic number)
+ * followed by W*H*3 raw bytes, rows top to bottom — a third of the size of the text form of src/lib.rs:151 and what
+ * image tools read fastest.  The reference writes P3 only. */
+int rt_write_ppm_p6(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height);
 
 /* ---- the host side of src/main.rs: scene file, texture images, file output ------------------- */
 
@@ -316,6 +320,14 @@ int rt_render_into_file(int fd, const rt_camera* cam, const rt_hittable* hittabl
 int rt_accel_render_into_file(int fd, const rt_camera* cam, const rt_hittable* hittables, size_t n_hittables,
                               const rt_texture* textures, size_t n_textures, uint32_t spp, uint32_t depth, uint64_t seed,
                               int device);
+/* The two calls above for a binary file: the caller writes "P6\nW H\n255\n" where src/main.rs:41-42 writes the P3
+ * header, and the pixels are appended as three raw bytes each in place of the "r g b\n" lines of src/lib.rs:151. */
+int rt_render_into_file_p6(int fd, const rt_camera* cam, const rt_hittable* hittables, size_t n_hittables,
+                           const rt_texture* textures, size_t n_textures, uint32_t spp, uint32_t depth, uint64_t seed,
+                           int device);
+int rt_accel_render_into_file_p6(int fd, const rt_camera* cam, const rt_hittable* hittables, size_t n_hittables,
+                                 const rt_texture* textures, size_t n_textures, uint32_t spp, uint32_t depth, uint64_t seed,
+                                 int device);
 
 /* Progressive renders.  The reference renders all samples in one go and keeps nothing (src/lib.rs:137-157); with
  * the counter-based sampler a render can stop after any sample index and continue later: a checkpoint file holds

@@ -153,14 +153,19 @@ double orc_render(const orc_scene* s, const Camera* cam, int traverse, int sampl
 // segments (optional) receives the number of segments each path traced.
 void orc_trace_paths(const orc_scene* s, const Camera* cam, int traverse, int sampler, const uint32_t* pixel,
                      const uint32_t* sample, size_t n, uint32_t depth, uint64_t seed, double* rgb, uint32_t* segments) {
-    std::vector<Candidate> scratch;
-    for (size_t k = 0; k < n; ++k) {
-        Sampler smp(sampler, seed, pixel[k], sample[k]);
-        Ray r = camera_ray(*cam, pixel[k] % cam->horiz_res, pixel[k] / cam->horiz_res, smp);
-        TraceCounters ctr;
-        Color c = trace(s->sc, traverse, r, depth, smp, scratch, &ctr);
-        rgb[3 * k] = c.r; rgb[3 * k + 1] = c.g; rgb[3 * k + 2] = c.b;
-        if (segments) segments[k] = uint32_t(ctr.segments);
+    // paths are independent (each has its own sampler): threads share nothing but the scene
+#pragma omp parallel
+    {
+        std::vector<Candidate> scratch;
+#pragma omp for schedule(dynamic, 8)
+        for (size_t k = 0; k < n; ++k) {
+            Sampler smp(sampler, seed, pixel[k], sample[k]);
+            Ray r = camera_ray(*cam, pixel[k] % cam->horiz_res, pixel[k] / cam->horiz_res, smp);
+            TraceCounters ctr;
+            Color c = trace(s->sc, traverse, r, depth, smp, scratch, &ctr);
+            rgb[3 * k] = c.r; rgb[3 * k + 1] = c.g; rgb[3 * k + 2] = c.b;
+            if (segments) segments[k] = uint32_t(ctr.segments);
+        }
     }
 }
 
@@ -168,13 +173,17 @@ void orc_trace_paths(const orc_scene* s, const Camera* cam, int traverse, int sa
 void orc_path_segments(const orc_scene* s, const Camera* cam, int traverse, int sampler, const uint32_t* pixel,
                        const uint32_t* sample, size_t n, uint32_t depth, uint64_t seed, uint32_t max_segments,
                        int32_t* seg_id, double* seg_t, uint32_t* n_seg) {
-    std::vector<Candidate> scratch;
-    for (size_t k = 0; k < n; ++k) {
-        Sampler smp(sampler, seed, pixel[k], sample[k]);
-        Ray r = camera_ray(*cam, pixel[k] % cam->horiz_res, pixel[k] / cam->horiz_res, smp);
-        SegmentLog log{seg_id + k * max_segments, seg_t + k * max_segments, max_segments, 0};
-        trace(s->sc, traverse, r, depth, smp, scratch, nullptr, &log);
-        n_seg[k] = log.n;
+#pragma omp parallel
+    {
+        std::vector<Candidate> scratch;
+#pragma omp for schedule(dynamic, 8)
+        for (size_t k = 0; k < n; ++k) {
+            Sampler smp(sampler, seed, pixel[k], sample[k]);
+            Ray r = camera_ray(*cam, pixel[k] % cam->horiz_res, pixel[k] / cam->horiz_res, smp);
+            SegmentLog log{seg_id + k * max_segments, seg_t + k * max_segments, max_segments, 0};
+            trace(s->sc, traverse, r, depth, smp, scratch, nullptr, &log);
+            n_seg[k] = log.n;
+        }
     }
 }
 

@@ -135,6 +135,7 @@ PROTOTYPES = {
     "rt_trace_paths": (_i, [_vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts), _vp, _vp, _sz, _vp]),
     "rt_trace_path_segments": (_i, [_vp, C.POINTER(rt_camera), C.POINTER(rt_render_opts), _vp, _vp, _sz, _vp, _u32, _vp, _vp, _vp]),
     "rt_write_ppm": (_i, [C.c_char_p, _vp, _u32, _u32]),
+    "rt_write_ppm_p6": (_i, [C.c_char_p, _vp, _u32, _u32]),
     "rt_finalize": (_i, [_vp, _sz, _u32, _vp]),
     "rt_checkpoint_save": (_i, [C.c_char_p, _vp, _vp]),
     "rt_checkpoint_load": (_i, [C.c_char_p, _vp, _vp, _sz]),
@@ -148,6 +149,8 @@ PROTOTYPES = {
     "rt_free": (None, [_vp]),
     "rt_render_into_file": (_i, [_i, C.POINTER(rt_camera), _vp, _sz, C.POINTER(rt_texture), _sz, _u32, _u32, _u64, _i]),
     "rt_accel_render_into_file": (_i, [_i, C.POINTER(rt_camera), _vp, _sz, C.POINTER(rt_texture), _sz, _u32, _u32, _u64, _i]),
+    "rt_render_into_file_p6": (_i, [_i, C.POINTER(rt_camera), _vp, _sz, C.POINTER(rt_texture), _sz, _u32, _u32, _u64, _i]),
+    "rt_accel_render_into_file_p6": (_i, [_i, C.POINTER(rt_camera), _vp, _sz, C.POINTER(rt_texture), _sz, _u32, _u32, _u64, _i]),
 }
 
 

@@ -272,6 +272,12 @@ def write_ppm(path, rgb8):
     check(lib.rt_write_ppm(os.fsencode(path), ptr(a), a.shape[1], a.shape[0]))
 
 
+def write_ppm_p6(path, rgb8):
+    """Binary PPM: the header of src/main.rs:41 with the magic number P6, then the raw bytes."""
+    a = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    check(lib.rt_write_ppm_p6(os.fsencode(path), ptr(a), a.shape[1], a.shape[0]))
+
+
 def ppm_header(cam):
     """src/main.rs:41."""
     return "P3\n%d %d\n255\n" % (cam.horiz_res, cam.vert_res)

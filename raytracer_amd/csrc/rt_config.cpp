@@ -413,8 +413,25 @@ int write_lines(int fd, const uint8_t* rgb8, size_t n_pixels) {
     return RT_OK;
 }
 
+// the pixels as three raw bytes each (the body of a binary "P6" file) appended to fd
+int write_raw(int fd, const uint8_t* rgb8, size_t n_pixels) {
+    const uint8_t* p = rgb8;
+    size_t left = n_pixels * 3;
+    while (left) {
+        ssize_t w = ::write(fd, p, left < (size_t(1) << 24) ? left : (size_t(1) << 24));
+        if (w < 0) {
+            if (errno == EINTR) continue;
+            return fail(RT_ERR_IO, "Unable to write colors.: %s", std::strerror(errno));
+        }
+        p += w;
+        left -= size_t(w);
+    }
+    return RT_OK;
+}
+
 int render_into_fd(int fd, const rt_camera* cam, const rt_hittable* hittables, size_t n, const rt_texture* textures,
-                   size_t n_textures, uint32_t spp, uint32_t depth, uint64_t seed, int device, bool covering_tree) {
+                   size_t n_textures, uint32_t spp, uint32_t depth, uint64_t seed, int device, bool covering_tree,
+                   bool binary = false) {
     if (!cam || (!hittables && n)) return fail(RT_ERR_INVALID_ARGUMENT, "render_into_file: null argument");
     if (spp == 0) return fail(RT_ERR_INVALID_ARGUMENT, "render_into_file: zero samples per pixel");
     if (covering_tree)
@@ -434,7 +451,7 @@ int render_into_fd(int fd, const rt_camera* cam, const rt_hittable* hittables, s
     int rc = rt_render(scene, cam, &opts, nullptr, rgb8.data());
     rt_scene_destroy(scene);  // the reference drops the tree at return (src/lib.rs:162)
     if (rc) return rc;
-    return write_lines(fd, rgb8.data(), n_pixels);
+    return binary ? write_raw(fd, rgb8.data(), n_pixels) : write_lines(fd, rgb8.data(), n_pixels);
 }
 
 }  // namespace
@@ -491,6 +508,18 @@ int rt_accel_render_into_file(int fd, const rt_camera* cam, const rt_hittable* h
                               const rt_texture* textures, size_t n_textures, uint32_t spp, uint32_t depth, uint64_t seed,
                               int device) {
     return rt::render_into_fd(fd, cam, hittables, n_hittables, textures, n_textures, spp, depth, seed, device, true);
+}
+
+int rt_render_into_file_p6(int fd, const rt_camera* cam, const rt_hittable* hittables, size_t n_hittables,
+                           const rt_texture* textures, size_t n_textures, uint32_t spp, uint32_t depth, uint64_t seed,
+                           int device) {
+    return rt::render_into_fd(fd, cam, hittables, n_hittables, textures, n_textures, spp, depth, seed, device, false, true);
+}
+
+int rt_accel_render_into_file_p6(int fd, const rt_camera* cam, const rt_hittable* hittables, size_t n_hittables,
+                                 const rt_texture* textures, size_t n_textures, uint32_t spp, uint32_t depth, uint64_t seed,
+                                 int device) {
+    return rt::render_into_fd(fd, cam, hittables, n_hittables, textures, n_textures, spp, depth, seed, device, true, true);
 }
 
 }  // extern "C"

@@ -1777,6 +1777,8 @@ double camera_abs(const rt_camera& c) {
 
 }  // namespace
 
+static void rt_multi_cache_forget(const rt_scene* scene);  // rt_render_multi's buffers for a handle list naming this scene
+
 extern "C" {
 
 int rt_device_count(void) {
@@ -1788,6 +1790,7 @@ int rt_device_count(void) {
 void rt_scene_destroy(rt_scene* scene) {
     if (!scene) return;
     DeviceGuard guard;
+    rt_multi_cache_forget(scene);
     (void)hipSetDevice(scene->device);
     if (scene->ev_done) { (void)hipEventSynchronize(scene->ev_done); (void)hipEventDestroy(scene->ev_done); }
     if (scene->d_partials) (void)hipFree(scene->d_partials);
@@ -2539,6 +2542,46 @@ std::mutex g_rccl_mutex;
 
 }  // namespace
 
+namespace {
+
+// What a multi-device render needs besides the scenes: one stream and one frame buffer per handle, the landing slots
+// and the 8-bit frame on the first device, one event per handle.  Kept between calls for the same handle list and
+// frame size (a second call allocates nothing); replaced when either changes, dropped when one of its scenes is destroyed.
+struct MultiCache {
+    std::vector<rt_scene*> scenes;
+    size_t n_pixels = 0;
+    std::vector<float*> d_sum;
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> landed;
+    float* d_land = nullptr;   // n_scenes - 1 slots on the first device (peer path)
+    uint8_t* d_rgb = nullptr;  // on the first device
+    void release() {
+        for (size_t g = 0; g < scenes.size(); ++g) {
+            if (hipSetDevice(scenes[g]->device) != hipSuccess) continue;
+            if (g < streams.size() && streams[g]) { (void)hipStreamSynchronize(streams[g]); (void)hipStreamDestroy(streams[g]); }
+            if (g < landed.size() && landed[g]) (void)hipEventDestroy(landed[g]);
+            if (g < d_sum.size() && d_sum[g]) (void)hipFree(d_sum[g]);
+        }
+        if (!scenes.empty() && hipSetDevice(scenes[0]->device) == hipSuccess) {
+            if (d_land) (void)hipFree(d_land);
+            if (d_rgb) (void)hipFree(d_rgb);
+        }
+        scenes.clear(); d_sum.clear(); streams.clear(); landed.clear();
+        d_land = nullptr; d_rgb = nullptr; n_pixels = 0;
+    }
+};
+MultiCache g_multi;
+std::mutex g_multi_mutex;
+
+}  // namespace
+
+// called by rt_scene_destroy: the cache must not outlive a scene it names
+static void rt_multi_cache_forget(const rt_scene* scene) {
+    std::lock_guard<std::mutex> lock(g_multi_mutex);
+    for (const rt_scene* s : g_multi.scenes)
+        if (s == scene) { g_multi.release(); return; }
+}
+
 int rt_render_multi(rt_scene* const* scenes, size_t n_scenes, const rt_camera* cam, const rt_render_opts* opts, float* sum_rgb,
                     uint8_t* rgb8) {
     if (!scenes || n_scenes == 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_multi: no scene handles");
@@ -2564,7 +2607,7 @@ int rt_render_multi(rt_scene* const* scenes, size_t n_scenes, const rt_camera* c
     // How the partial images meet on the first device.  "rccl": one ncclReduce(sum) to rank 0 over xGMI (needs one
     // handle per DIFFERENT device; the library picks the order of the additions).  "peer": every device copies its
     // image into a landing slot of its own on the first device, all copies in flight at once, and one kernel adds the
-    // slots in handle order.  Default: rccl where it applies and loads, else peer.
+    // slots in handle order.  Default: rccl where it applies, loads and sets up its communicators, else peer.
     const char* how = std::getenv("RT_MULTI_REDUCE");
     const bool force_rccl = how && std::strcmp(how, "rccl") == 0, force_peer = how && std::strcmp(how, "peer") == 0;
     if (how && !force_rccl && !force_peer) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_multi: RT_MULTI_REDUCE is '%s' (rccl or peer)", how);
@@ -2576,84 +2619,99 @@ int rt_render_multi(rt_scene* const* scenes, size_t n_scenes, const rt_camera* c
         if (!g_rccl.load()) {
             if (force_rccl) return fail(RT_ERR_DEVICE, "rt_render_multi: librccl.so could not be loaded: %s", dlerror());
             use_rccl = false;
-            rccl_lock.unlock();
+        } else if (int crc = g_rccl.communicators(devs)) {
+            // a machine on which RCCL cannot set up these communicators still renders: the peer copies need nothing
+            // but HIP.  Only a caller that asked for RCCL by name gets the error (rt_last_error has RCCL's own text).
+            if (force_rccl) return crc;
+            use_rccl = false;
         }
+        if (!use_rccl) rccl_lock.unlock();
     }
 
-    std::vector<float*> d_sum(n_scenes, nullptr);
-    std::vector<hipStream_t> streams(n_scenes, nullptr);
-    std::vector<hipEvent_t> landed(n_scenes, nullptr);
-    float* d_land = nullptr;  // n_scenes - 1 landing slots on the first device (peer path)
-    uint8_t* d_rgb = nullptr;
+    std::lock_guard<std::mutex> cache_lock(g_multi_mutex);
     int rc = RT_OK;
     auto chk = [&](hipError_t e, const char* what) {
         if (e != hipSuccess && rc == RT_OK) rc = fail(RT_ERR_DEVICE, "rt_render_multi: %s failed: %s", what, hipGetErrorString(e));
     };
-    if (use_rccl) rc = g_rccl.communicators(devs);
-    if (rc == RT_OK && !use_rccl && n_scenes > 1) {
-        chk(hipSetDevice(dev0), "hipSetDevice");
-        chk(hipMalloc(reinterpret_cast<void**>(&d_land), bytes * (n_scenes - 1)), "hipMalloc");
+    MultiCache& mc = g_multi;
+    const std::vector<rt_scene*> key(scenes, scenes + n_scenes);
+    if (mc.scenes != key || mc.n_pixels != n_pixels) {
+        mc.release();
+        mc.scenes = key;
+        mc.n_pixels = n_pixels;
+        mc.d_sum.assign(n_scenes, nullptr);
+        mc.streams.assign(n_scenes, nullptr);
+        mc.landed.assign(n_scenes, nullptr);
+        for (size_t g = 0; g < n_scenes && rc == RT_OK; ++g) {
+            chk(hipSetDevice(devs[g]), "hipSetDevice");
+            chk(hipStreamCreateWithFlags(&mc.streams[g], hipStreamNonBlocking), "hipStreamCreate");
+            chk(hipMalloc(reinterpret_cast<void**>(&mc.d_sum[g]), bytes), "hipMalloc");
+            chk(hipEventCreateWithFlags(&mc.landed[g], hipEventDisableTiming), "hipEventCreate");
+            if (rc == RT_OK && devs[g] != dev0) {  // direct xGMI access where the pair allows it; the copies work either way
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, devs[g], dev0) == hipSuccess && can) {
+                    const hipError_t e = hipDeviceEnablePeerAccess(dev0, 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) chk(e, "hipDeviceEnablePeerAccess");
+                    (void)hipGetLastError();
+                }
+            }
+        }
+        if (rc == RT_OK) {
+            chk(hipSetDevice(dev0), "hipSetDevice");
+            if (n_scenes > 1) chk(hipMalloc(reinterpret_cast<void**>(&mc.d_land), bytes * (n_scenes - 1)), "hipMalloc");
+            chk(hipMalloc(reinterpret_cast<void**>(&mc.d_rgb), n_pixels * 3), "hipMalloc");
+        }
+        // the partial sums of chunked renders, so that the render calls below find them in place
+        for (size_t g = 0; g < n_scenes && rc == RT_OK; ++g) {
+            rt_render_opts o = *opts;
+            o.sample_begin = opts->sample_begin + uint32_t(uint64_t(spp) * g / n_scenes);
+            o.sample_end = opts->sample_begin + uint32_t(uint64_t(spp) * (g + 1) / n_scenes);
+            rc = rt_scene_reserve(scenes[g], cam, &o);
+        }
+        if (rc != RT_OK) { mc.release(); return rc; }
     }
     // every device traces its share of the sample indices at the same time, each on a stream of its own; on the peer
     // path its copy to the first device follows on the same stream
     for (size_t g = 0; g < n_scenes && rc == RT_OK; ++g) {
-        chk(hipSetDevice(devs[g]), "hipSetDevice");
-        chk(hipStreamCreateWithFlags(&streams[g], hipStreamNonBlocking), "hipStreamCreate");
-        chk(hipMalloc(reinterpret_cast<void**>(&d_sum[g]), bytes), "hipMalloc");
-        if (rc != RT_OK) break;
         rt_render_opts o = *opts;
         o.sample_begin = opts->sample_begin + uint32_t(uint64_t(spp) * g / n_scenes);
         o.sample_end = opts->sample_begin + uint32_t(uint64_t(spp) * (g + 1) / n_scenes);
-        rc = rt_render_device(scenes[g], cam, &o, d_sum[g], streams[g]);
+        rc = rt_render_device(scenes[g], cam, &o, mc.d_sum[g], mc.streams[g]);
         if (rc != RT_OK || use_rccl || g == 0) continue;
-        if (devs[g] != dev0) {  // direct xGMI access where the pair allows it; the copy below works either way
-            int can = 0;
-            if (hipDeviceCanAccessPeer(&can, devs[g], dev0) == hipSuccess && can) {
-                const hipError_t e = hipDeviceEnablePeerAccess(dev0, 0);
-                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) chk(e, "hipDeviceEnablePeerAccess");
-                (void)hipGetLastError();
-            }
-        }
-        chk(hipMemcpyPeerAsync(d_land + (g - 1) * n_channels, dev0, d_sum[g], devs[g], bytes, streams[g]), "hipMemcpyPeerAsync");
-        chk(hipEventCreateWithFlags(&landed[g], hipEventDisableTiming), "hipEventCreate");
-        chk(hipEventRecord(landed[g], streams[g]), "hipEventRecord");
+        chk(hipSetDevice(devs[g]), "hipSetDevice");
+        chk(hipMemcpyPeerAsync(mc.d_land + (g - 1) * n_channels, dev0, mc.d_sum[g], devs[g], bytes, mc.streams[g]), "hipMemcpyPeerAsync");
+        chk(hipEventRecord(mc.landed[g], mc.streams[g]), "hipEventRecord");
     }
     // the one exchange
     if (rc == RT_OK && use_rccl) {
         int r = g_rccl.GroupStart();
         for (size_t g = 0; g < n_scenes && r == 0; ++g) {
             chk(hipSetDevice(devs[g]), "hipSetDevice");
-            r = g_rccl.Reduce(d_sum[g], d_sum[g], n_channels, /*ncclFloat32*/ 7, /*ncclSum*/ 0, 0, g_rccl.comms[g], streams[g]);
+            r = g_rccl.Reduce(mc.d_sum[g], mc.d_sum[g], n_channels, /*ncclFloat32*/ 7, /*ncclSum*/ 0, 0, g_rccl.comms[g], mc.streams[g]);
         }
         const int r_end = g_rccl.GroupEnd();
         if (r == 0) r = r_end;
         if (r != 0 && rc == RT_OK) rc = fail(RT_ERR_DEVICE, "rt_render_multi: ncclReduce failed: %s", g_rccl.GetErrorString(r));
     } else if (rc == RT_OK && n_scenes > 1) {
         chk(hipSetDevice(dev0), "hipSetDevice");
-        for (size_t g = 1; g < n_scenes; ++g) chk(hipStreamWaitEvent(streams[0], landed[g], 0), "hipStreamWaitEvent");
+        for (size_t g = 1; g < n_scenes; ++g) chk(hipStreamWaitEvent(mc.streams[0], mc.landed[g], 0), "hipStreamWaitEvent");
         if (rc == RT_OK) {
-            hipLaunchKernelGGL(combine_kernel, dim3(uint32_t((n_channels + kBlock - 1) / kBlock)), dim3(kBlock), 0, streams[0], d_land,
-                               uint32_t(n_scenes - 1), n_channels, 1u, d_sum[0]);
+            hipLaunchKernelGGL(combine_kernel, dim3(uint32_t((n_channels + kBlock - 1) / kBlock)), dim3(kBlock), 0, mc.streams[0], mc.d_land,
+                               uint32_t(n_scenes - 1), n_channels, 1u, mc.d_sum[0]);
             chk(hipGetLastError(), "combine_kernel");
         }
     }
     if (rc == RT_OK) chk(hipSetDevice(dev0), "hipSetDevice");
-    if (rc == RT_OK && rgb8) {
-        chk(hipMalloc(reinterpret_cast<void**>(&d_rgb), n_pixels * 3), "hipMalloc");
-        if (rc == RT_OK) rc = rt_finalize_device(scenes[0], d_sum[0], n_pixels, spp, d_rgb, streams[0]);
-    }
-    if (rc == RT_OK) chk(hipStreamSynchronize(streams[0]), "kernel execution");
-    if (rc == RT_OK && sum_rgb) chk(hipMemcpy(sum_rgb, d_sum[0], bytes, hipMemcpyDeviceToHost), "download");
-    if (rc == RT_OK && rgb8) chk(hipMemcpy(rgb8, d_rgb, n_pixels * 3, hipMemcpyDeviceToHost), "download");
-    for (size_t g = 0; g < n_scenes; ++g) {
-        if (hipSetDevice(devs[g]) != hipSuccess) continue;
-        if (streams[g]) { (void)hipStreamSynchronize(streams[g]); (void)hipStreamDestroy(streams[g]); }
-        if (landed[g]) (void)hipEventDestroy(landed[g]);
-        if (d_sum[g]) (void)hipFree(d_sum[g]);
-    }
-    if (hipSetDevice(dev0) == hipSuccess) {
-        if (d_land) (void)hipFree(d_land);
-        if (d_rgb) (void)hipFree(d_rgb);
+    if (rc == RT_OK && rgb8) rc = rt_finalize_device(scenes[0], mc.d_sum[0], n_pixels, spp, mc.d_rgb, mc.streams[0]);
+    // the first device's stream ends with everything the result depends on; the other streams have nothing after
+    // their copy (peer) or their part of the reduce (RCCL), and the next call's renders wait for each scene's own event
+    if (rc == RT_OK) chk(hipStreamSynchronize(mc.streams[0]), "kernel execution");
+    if (rc == RT_OK && sum_rgb) chk(hipMemcpy(sum_rgb, mc.d_sum[0], bytes, hipMemcpyDeviceToHost), "download");
+    if (rc == RT_OK && rgb8) chk(hipMemcpy(rgb8, mc.d_rgb, n_pixels * 3, hipMemcpyDeviceToHost), "download");
+    if (rc != RT_OK) {  // leave nothing in flight behind an error, and nothing cached that may be half set up
+        for (size_t g = 0; g < n_scenes; ++g)
+            if (hipSetDevice(devs[g]) == hipSuccess && mc.streams[g]) (void)hipStreamSynchronize(mc.streams[g]);
+        mc.release();
     }
     return rc;
 }

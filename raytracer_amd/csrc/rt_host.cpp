@@ -210,6 +210,17 @@ int rt_write_ppm(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t
     return ok ? RT_OK : fail(RT_ERR_IO, "rt_write_ppm: write to %s failed", path);
 }
 
+int rt_write_ppm_p6(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height) {
+    if (!path || !rgb8) return fail(RT_ERR_INVALID_ARGUMENT, "rt_write_ppm_p6: null argument");
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return fail(RT_ERR_IO, "rt_write_ppm_p6: cannot open %s", path);
+    const size_t n = size_t(width) * height * 3;
+    bool ok = std::fprintf(f, "P6\n%u %u\n255\n", width, height) > 0;  // the header of src/main.rs:41 with the binary magic number
+    ok = ok && (n == 0 || std::fwrite(rgb8, 1, n, f) == n);
+    if (std::fclose(f) != 0) ok = false;
+    return ok ? RT_OK : fail(RT_ERR_IO, "rt_write_ppm_p6: write to %s failed", path);
+}
+
 int rt_finalize(const float* sum_rgb, size_t n_pixels, uint32_t spp_total, uint8_t* rgb8) {
     if (!sum_rgb || !rgb8) return fail(RT_ERR_INVALID_ARGUMENT, "rt_finalize: null argument");
     if (spp_total == 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_finalize: zero samples");

@@ -22,6 +22,13 @@ def hip():
     return _hip
 
 
+def mem_free():
+    """Free device memory in bytes (hipMemGetInfo) of the current device."""
+    free, total = C.c_size_t(), C.c_size_t()
+    check(hip().hipMemGetInfo(C.byref(free), C.byref(total)), "hipMemGetInfo")
+    return free.value
+
+
 def check(status, what):
     if status != 0:
         raise RuntimeError("%s failed with HIP status %d" % (what, status))

@@ -100,6 +100,18 @@ def test_write_ppm_format(rt, tmp_path):
     assert e.value.status == 4
 
 
+def test_write_ppm_p6_byte_layout(rt, tmp_path):
+    # binary PPM: "P6\nW H\n255\n" then W*H*3 raw bytes, rows top to bottom
+    img = np.array([[[0, 1, 2], [255, 128, 7], [3, 4, 5]], [[10, 20, 30], [99, 100, 101], [6, 7, 8]]], dtype=np.uint8)
+    p = tmp_path / "image.ppm"
+    p.write_bytes(b"x" * 500)
+    rt.write_ppm_p6(str(p), img)
+    assert p.read_bytes() == b"P6\n3 2\n255\n" + img.tobytes()
+    with pytest.raises(rt.RtError) as e:
+        rt.write_ppm_p6(str(tmp_path / "no_such_dir" / "x.ppm"), img)
+    assert e.value.status == 4
+
+
 def test_scene_create_fails_loudly_without_a_gpu(rt):
     from raytracer_amd import _abi
 

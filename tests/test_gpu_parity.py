@@ -132,6 +132,7 @@ def _path_parity(scene, oscene, cam, ocam, ob, n_pixels, spp, depth, seed, trave
     oscene.set_dir_noise(DIR_ERR)
     try:
         ni, nt, nn = oscene.path_segments(ocam, pixel, sample, depth=depth, seed=seed, traverse=traverse, max_segments=m)
+        nwant = oscene.trace_paths(ocam, pixel, sample, depth=depth, seed=seed, traverse=traverse, sampler=ob.SAMPLER_DIRECT)
     finally:
         oscene.set_dir_noise(0.0)
     ok_n, in_n = within(nt, ni, nn)
@@ -143,6 +144,13 @@ def _path_parity(scene, oscene, cam, ocam, ob, n_pixels, spp, depth, seed, trave
     # direction error; the callers hold the device to min(0.999, that share)
     noise_same = np.all(ni == wi, axis=1) & (nn == wn)
     _path_parity.id_floor = min(0.999, float(noise_same[calm].mean()) - 0.0005) if calm.any() else 0.999
+    # and over ALL paths, glass included: past a refraction into a sphere the perturbed oracle parts from the
+    # unperturbed one as any second correct implementation does, so its shares of equal ID sequences and of equal
+    # colours are the bars for the device there too (binomial slack of three standard deviations)
+    noise_close = np.all(np.abs(nwant - want) <= 2e-4 * np.maximum(1.0, np.abs(want)), axis=1)
+    slack = lambda share: 3.0 * np.sqrt(max(share * (1.0 - share), 1e-4) / len(pixel))
+    _path_parity.all_id_floor = float(noise_same.mean()) - slack(float(noise_same.mean()))
+    _path_parity.all_close_floor = float(noise_close.mean()) - slack(float(noise_close.mean()))
     return got, want, close, same_ids, calm
 
 
@@ -153,7 +161,8 @@ def test_paths_match_oracle_one_by_one(scene1, oscene1, ob, rt):
     assert calm.mean() > 0.9
     assert same_ids[calm].mean() > 0.999, "ID sequences differ on %.5f of the paths without glass" % (1 - same_ids[calm].mean())
     assert close[calm].mean() > 0.998
-    assert same_ids.mean() > 0.97 and close.mean() > 0.97
+    assert same_ids.mean() >= _path_parity.all_id_floor, (same_ids.mean(), _path_parity.all_id_floor)
+    assert close.mean() >= _path_parity.all_close_floor, (close.mean(), _path_parity.all_close_floor)
     assert abs(got.mean() - want.mean()) < 5e-3 * want.mean()
 
 
@@ -583,17 +592,29 @@ def test_million_sphere_scene_primary_hits_and_render(rt, ob):
     want_ids, want_t, want_n, _ = ob.Scene(h).trace(o, d, ob.TRAVERSE_GATED_BRUTE)
     _check_hits(ids, t, nrm, want_ids, want_t, want_n)
     assert (want_ids > 0).sum() > 150  # small spheres, not only the ground
-    # 256 whole paths from the render kernel (tree in HBM, quantised nodes, assembly loop) against the oracle's
-    # scan over all million spheres
-    small = rt.Camera.build([0, 0, 0], [130, 40, 30], 1.0, 0.1, 16, 16)
+    # 2048 whole paths from the render kernel (tree in HBM, quantised nodes, assembly loop) against the oracle's
+    # scan over all million spheres; the bar is the share of glass-free paths that survives the stated direction
+    # error in the oracle itself
+    small = rt.Camera.build([0, 0, 0], [130, 40, 30], 1.0, 0.1, 64, 32)
     oscene = ob.Scene(h)
-    got = scene.render_paths(small, 1, depth=50, seed=7).reshape(256, 3).astype(np.float64)
-    pxs = np.arange(256, dtype=np.uint32)
-    want = oscene.trace_paths(_ocam(ob, small), pxs, np.zeros(256, np.uint32), depth=50, seed=7, traverse=ob.TRAVERSE_GATED_BRUTE)
-    wi, _, _ = oscene.path_segments(_ocam(ob, small), pxs, np.zeros(256, np.uint32), depth=50, seed=7, traverse=ob.TRAVERSE_GATED_BRUTE, max_segments=12)
+    n_paths = 64 * 32
+    got = scene.render_paths(small, 1, depth=50, seed=7).reshape(n_paths, 3).astype(np.float64)
+    pxs = np.arange(n_paths, dtype=np.uint32)
+    zeros = np.zeros(n_paths, np.uint32)
+    want = oscene.trace_paths(_ocam(ob, small), pxs, zeros, depth=50, seed=7, traverse=ob.TRAVERSE_GATED_BRUTE)
+    wi, _, _ = oscene.path_segments(_ocam(ob, small), pxs, zeros, depth=50, seed=7, traverse=ob.TRAVERSE_GATED_BRUTE, max_segments=12)
+    oscene.set_dir_noise(DIR_ERR)
+    try:
+        nwant = oscene.trace_paths(_ocam(ob, small), pxs, zeros, depth=50, seed=7, traverse=ob.TRAVERSE_GATED_BRUTE)
+    finally:
+        oscene.set_dir_noise(0.0)
     calm = ~np.any((wi >= 0) & (np.asarray(h["material"])[np.maximum(wi, 0)] == 2), axis=1)
-    close = np.all(np.abs(got - want) <= 2e-4 * np.maximum(1.0, np.abs(want)), axis=1)
-    assert calm.sum() > 200 and close[calm].mean() > 0.99, (calm.sum(), close[calm].mean())
+    tol = 2e-4 * np.maximum(1.0, np.abs(want))
+    close = np.all(np.abs(got - want) <= tol, axis=1)
+    noise_close = np.all(np.abs(nwant - want) <= tol, axis=1)
+    floor = min(0.998, float(noise_close[calm].mean()) - 0.001)
+    assert calm.sum() > 1500 and close[calm].mean() >= floor, (calm.sum(), close[calm].mean(), floor)
+    assert np.array_equal(got.astype(np.float32), scene.trace_paths(small, pxs, zeros, depth=50, seed=7))
     assert (wi[:, 0] > 0).sum() > 60  # the camera rays do reach the small spheres
     # full-size render: finite, reproducible, sample ranges add up, schedules agree
     from raytracer_amd import _abi
@@ -825,6 +846,52 @@ def test_render_multi_splits_samples_over_scene_handles(rt, scene1):
         rt.render_multi(scenes, cam, 2)  # fewer samples than devices
 
 
+def test_render_multi_second_call_allocates_nothing(rt, scene1):
+    """rt_render_multi keeps its streams, frame buffers, landing slots and events for a handle list: the second call
+    for the same list and frame size leaves the device's free memory as it was and takes about as long as the three
+    shares rendered one after the other (three handles on the one GPU cannot overlap), not milliseconds more."""
+    import ctypes as C
+    import time
+
+    import hip_mem
+    from raytracer_amd import _abi
+
+    h = rt.gen_scene(1)
+    scenes = [scene1, rt.Scene(h), rt.Scene(h)]
+    cam = rt.default_camera(1920, 1080)
+    spp = 30
+    first, _ = rt.render_multi(scenes, cam, spp, depth=50, seed=4, want_rgb8=False)
+    free0 = hip_mem.mem_free()
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        rt.render_multi(scenes, cam, spp, depth=50, seed=4, want_sum=False, want_rgb8=True)  # 6 MB back, not 25
+        times.append(time.perf_counter() - t0)
+    assert hip_mem.mem_free() == free0
+    again, _ = rt.render_multi(scenes, cam, spp, depth=50, seed=4, want_rgb8=False)
+    assert np.array_equal(first, again)
+    # the three shares as plain device renders, one after the other
+    buf = hip_mem.DeviceArray(1920 * 1080 * 3)
+    stream = hip_mem.Stream()
+    singles = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for g, sc in enumerate(scenes):
+            b, e = rt.sample_shard(spp, g, 3)
+            o = rt.Scene.opts(b, e, 50, 4)
+            _abi.check(_abi.lib.rt_render_device(sc.handle, C.byref(cam.c), C.byref(o), buf.ptr, stream.handle))
+        stream.synchronize()
+        singles.append(time.perf_counter() - t0)
+    # finalize + 6 MB download + two 25 MB device copies + the sum are the multi call's own work: 1 ms covers them
+    assert min(times) < min(singles) + 1.5e-3, (times, singles)
+    # a different frame size replaces the cache, and a destroyed scene drops it
+    small, _ = rt.render_multi(scenes, rt.default_camera(64, 48), 6, depth=10, seed=1)
+    assert np.isfinite(small).all()
+    del scenes[2]
+    s2, _ = rt.render_multi(scenes, rt.default_camera(64, 48), 6, depth=10, seed=1)
+    assert np.allclose(s2, small, rtol=2e-6, atol=1e-6)
+
+
 def test_render_multi_reduces_through_rccl(rt):
     """The RCCL branch of rt_render_multi with the one communicator a one-GPU box allows (RT_MULTI_REDUCE=rccl, one
     handle): librccl is found and bound, ncclCommInitAll / ncclReduce run on the render's stream, and the image that
@@ -842,16 +909,15 @@ def test_render_multi_reduces_through_rccl(rt):
         "try:\n"
         "    one, q1 = rt.render_multi([sc], cam, 10, depth=50, seed=4)\n"
         "except rt.RtError as e:\n"
-        "    print('NO-RCCL' if ('could not be loaded' in str(e) or 'ncclCommInitAll failed' in str(e)) else 'ERROR', e); sys.exit(0)\n"
+        "    print('NO-RCCL' if 'could not be loaded' in str(e) else 'ERROR', e); sys.exit(0)\n"
         "print('EQUAL' if np.array_equal(one, whole) and np.array_equal(q1, q) else 'DIFFERENT')\n"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    try:
-        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=100)
-    except subprocess.TimeoutExpired:
-        pytest.skip("RCCL did not set up its communicator within 100 s on this machine")
+    # a communicator that cannot be set up (the RCCL error string is in the output) or a call that does not come back
+    # is a failure; only a machine without librccl skips
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     if "NO-RCCL" in out.stdout:
-        pytest.skip("RCCL cannot be loaded or cannot set up a communicator on this machine: " + out.stdout.strip()[-200:])
+        pytest.skip("librccl.so cannot be loaded on this machine: " + out.stdout.strip()[-200:])
     assert "EQUAL" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 

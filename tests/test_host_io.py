@@ -219,6 +219,13 @@ def test_render_into_file_entry_points(rt, tmp_path):
                                                       2, 10, 0, 0))
     _, want = rt.Scene(spheres).render(cam, 2, depth=10, seed=0, want_sum=False)
     assert np.array_equal(_read_ppm(path), want.reshape(24, 40, 3))
+    # the binary variants append the same pixels as raw bytes behind a P6 header
+    for fn, hs, tx, nt in ((_abi.lib.rt_accel_render_into_file_p6, spheres, None, 0), (_abi.lib.rt_render_into_file_p6, spheres, None, 0)):
+        with open(path, "wb") as f:
+            f.write(b"P6\n40 24\n255\n")
+            f.flush()
+            _abi.check(fn(f.fileno(), C.byref(cam.c), hs.ctypes.data, len(hs), tx, nt, 2, 10, 0, 0))
+        assert path.read_bytes() == b"P6\n40 24\n255\n" + want.tobytes()
 
 
 def test_checkpoint_file_round_trip(rt, tmp_path):

@@ -50,6 +50,7 @@ constexpr int kIters = 256, kUnroll = 16;
 
 #define T_FMA32(R) "v_fma_f32 " #R ", " #R ", %8, %9\n\t"
 #define T_FMAMIX(R) "v_fma_mix_f32 " #R ", " #R ", %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+#define T_DOT2(R) "v_dot2_f32_f16 " #R ", " #R ", %8, %9 neg_hi:[0,1,0] clamp\n\t"
 #define T_MIN32(R) "v_min_f32 " #R ", " #R ", %8\n\t"
 #define T_MAX3(R) "v_max3_f32 " #R ", " #R ", %8, %9\n\t"
 #define T_CNDMASK(R) "v_cndmask_b32 " #R ", " #R ", %8, vcc\n\t"
@@ -73,12 +74,14 @@ constexpr int kIters = 256, kUnroll = 16;
 #define T_LDEXP64(R) "v_ldexp_f64 " #R ", " #R ", 3\n\t"
 #define T_MAD64(R) "v_mad_u64_u32 " #R ", vcc, %8, %9, " #R "\n\t"
 #define T_PKFMA(R) "v_pk_fma_f32 " #R ", " #R ", %8, %9\n\t"
+#define T_PKADDC(R) "v_pk_add_f32 " #R ", " #R ", %8 neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
 #define T_PKMUL(R) "v_pk_mul_f32 " #R ", " #R ", %8\n\t"
 #define T_CMP64(R) "v_cmp_lt_f64 vcc, " #R ", %8\n\t"
 #define T_CVT3264(R) "v_cvt_f64_f32 " #R ", %L8\n\t"
 
 KERNEL_V32(k_fma32, T_FMA32)
 KERNEL_V32(k_fmamix, T_FMAMIX)
+KERNEL_V32(k_dot2, T_DOT2)
 KERNEL_V32(k_min32, T_MIN32)
 KERNEL_V32(k_max3, T_MAX3)
 KERNEL_V32(k_cndmask, T_CNDMASK)
@@ -102,6 +105,7 @@ KERNEL_V64(k_rcp64, T_RCP64)
 KERNEL_V64(k_ldexp64, T_LDEXP64)
 KERNEL_V64(k_pkfma, T_PKFMA)
 KERNEL_V64(k_pkmul, T_PKMUL)
+KERNEL_V64(k_pkaddc, T_PKADDC)
 KERNEL_V64(k_cmp64, T_CMP64)
 
 // the same instruction as ONE dependent chain (every instruction reads the result of the one before)
@@ -262,6 +266,7 @@ int main() {
     }
     ROW("v_fma_f32", k_fma32)
     ROW("v_fma_mix_f32", k_fmamix)
+    ROW("v_dot2_f32_f16", k_dot2)
     ROW("v_min_f32", k_min32)
     ROW("v_max3_f32", k_max3)
     ROW("v_cndmask_b32", k_cndmask)
@@ -279,6 +284,7 @@ int main() {
     ROW("v_sin_f32", k_sin)
     ROW("v_pk_fma_f32", k_pkfma)
     ROW("v_pk_mul_f32", k_pkmul)
+    ROW("v_pk_add_f32 clamp", k_pkaddc)
     ROW("v_fma_f64", k_fma64)
     ROW("v_mul_f64", k_mul64)
     ROW("v_add_f64", k_add64)
