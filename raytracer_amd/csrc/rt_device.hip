@@ -70,6 +70,7 @@ struct SceneDev {
     float qbase[3], qstep[3];  // grid of nodes32
     float hbase[3], hstep[3];  // the f16 boxes of the LDS-resident tree are (plane - hbase) / hstep
     float eps_rel;             // origin widening of the render kernels' descent, which works relative to qbase / hbase
+    float t_scale;             // the render kernels' descent measures ray parameters in units of 1 / t_scale, a length no segment of this scene reaches
     const double4* sph;     // the n_tree spheres of the BVH in leaf order, then the n_wide spheres kept out of it
     const DiscDev* discs;   // scene order
     const float4* mat;      // spheres in leaf order, then discs: albedo rgb + (fuzz | refractive index)
@@ -832,7 +833,9 @@ __device__ __forceinline__ void trav_begin(const SceneDev& S, const Tables& Tb, 
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const float d = df[a];
-        const float i = (fabsf(d) >= 1.0e-18f) ? fast_rcp(d) : copysignf(1.0e18f, d);
+        // 1 / d in units of the scene's parameter scale: every parameter that can matter then lies in [0, 1], and the
+        // clamp modifier of the instruction that forms the z entry parameters does the work of max(., 0)
+        const float i = ((fabsf(d) >= 1.0e-18f) ? fast_rcp(d) : copysignf(1.0e18f, d)) * S.t_scale;
         const float base = GRID ? S.qbase[a] : S.hbase[a], step = GRID ? S.qstep[a] : S.hstep[a];
         const float rel = float(double(base) - o64[a]);  // base - origin, rounded once
         T.inv[a] = step * i;
@@ -843,7 +846,7 @@ __device__ __forceinline__ void trav_begin(const SceneDev& S, const Tables& Tb, 
             T.A_E[a] = float2v{T.A[a], T.E[a]};
         }
     }
-    T.tmax = (T.best.k >= 0) ? float(T.best.t) * (1.0f + 4.0e-7f) : 3.0e38f;
+    T.tmax = (T.best.k >= 0) ? float(T.best.t) * (1.0f + 4.0e-7f) * S.t_scale : 3.0e38f;
 }
 
 // Entry and exit parameters of the two child boxes of a node, from their centres c and half extents h (node units).
@@ -858,9 +861,10 @@ __device__ __forceinline__ void slab2(const Trav& T, const float c0[3], const fl
         n0[a] = tc0 - w0; f0[a] = tc0 + w0;
         n1[a] = tc1 - w1; f1[a] = tc1 + w1;
     }
-    *en0 = fmaxf(fmaxf(n0[0], n0[1]), fmaxf(n0[2], 0.0f));
+    // entry on z clamped to [0, 1] like the assembly loops' clamp modifier (1 is beyond every box: see SceneDev::t_scale)
+    *en0 = fmaxf(fmaxf(n0[0], n0[1]), fminf(fmaxf(n0[2], 0.0f), 1.0f));
     *ex0 = fminf(fminf(f0[0], f0[1]), fminf(f0[2], T.tmax));
-    *en1 = fmaxf(fmaxf(n1[0], n1[1]), fmaxf(n1[2], 0.0f));
+    *en1 = fmaxf(fmaxf(n1[0], n1[1]), fminf(fmaxf(n1[2], 0.0f), 1.0f));
     *ex1 = fminf(fminf(f1[0], f1[1]), fminf(f1[2], T.tmax));
 }
 
@@ -981,10 +985,8 @@ __device__ __forceinline__ void inner_loop_lds16(Trav& T, uint32_t q0_addr, uint
         "v_fma_mix_f32 v122, v125, |%[iz]|, %[ez] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
         "v_fma_mix_f32 v123, v125, |%[iz]|, %[ez] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
         "v_pk_add_f32 v[124:125], v[120:121], v[122:123]\n\t"   // far parameters
-        "v_pk_add_f32 v[122:123], v[120:121], v[122:123] neg_lo:[0,1] neg_hi:[0,1]\n\t"   // near parameters
+        "v_pk_add_f32 v[122:123], v[120:121], v[122:123] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"   // near parameters, clamped to [0, 1]: max(., 0) for free
         // near x / y / z = v116,117 / v118,119 / v122,123; far = v112,113 / v114,115 / v124,125 (child 0, child 1)
-        "v_max_f32_e32 v122, 0, v122\n\t"
-        "v_max_f32_e32 v123, 0, v123\n\t"
         "v_min_f32_e32 v124, v124, %[tmax]\n\t"
         "v_min_f32_e32 v125, v125, %[tmax]\n\t"
         "v_max3_f32 v116, v116, v118, v122\n\t"   // entry parameter of child 0
@@ -1110,10 +1112,8 @@ __device__ __forceinline__ void inner_loop_hbm(Trav& T, const Node32* nodes32, i
         "v_pk_fma_f32 v[120:121], v[120:121], %[pz], %[qz] op_sel_hi:[1,0,0]\n\t"   // centres * inv + A, both children
         "v_pk_fma_f32 v[122:123], v[122:123], %[pz], %[qz] op_sel:[0,1,1] op_sel_hi:[1,1,1]\n\t"   // half extents * |inv| + E
         "v_pk_add_f32 v[124:125], v[120:121], v[122:123]\n\t"   // far parameters
-        "v_pk_add_f32 v[122:123], v[120:121], v[122:123] neg_lo:[0,1] neg_hi:[0,1]\n\t"   // near parameters
+        "v_pk_add_f32 v[122:123], v[120:121], v[122:123] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"   // near parameters, clamped to [0, 1]: max(., 0) for free
         // near x / y / z = v116,117 / v118,119 / v122,123; far = v112,113 / v114,115 / v124,125 (child 0, child 1)
-        "v_max_f32_e32 v122, 0, v122\n\t"
-        "v_max_f32_e32 v123, 0, v123\n\t"
         "v_min_f32_e32 v124, v124, %[tmax]\n\t"
         "v_min_f32_e32 v125, v125, %[tmax]\n\t"
         "v_max3_f32 v116, v116, v118, v122\n\t"   // entry parameter of child 0
@@ -1181,10 +1181,10 @@ __device__ __forceinline__ void inner_loop_hbm(Trav& T, const Node32* nodes32, i
 }
 
 template <bool LDS16, int BLOCK>
-__device__ __forceinline__ void leaf_step(const Tables& Tb, const Path& p, Trav& T) {
+__device__ __forceinline__ void leaf_step(const Tables& Tb, const Path& p, Trav& T, float t_scale) {
     const int32_t k = ~T.node;
     const bool better = sphere_candidate(Tb.sph[k], k, Tb.prim_id[k], p, true, T.best);
-    T.tmax = better ? float(T.best.t) * (1.0f + 4.0e-7f) : T.tmax;
+    T.tmax = better ? float(T.best.t) * (1.0f + 4.0e-7f) * t_scale : T.tmax;
     pop<BLOCK>(T);
 }
 
@@ -1376,7 +1376,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
             const uint64_t t_leaf = TIMING ? cycle_stamp() : 0;
             if (TIMING) cyc[2] += t_leaf - t_inner;
             if (STATS && __any(T.node < 0 && T.node != kLeafSentinel)) { st[2]++; if (T.node < 0 && T.node != kLeafSentinel) st[3]++; }
-            if (T.node < 0 && T.node != kLeafSentinel) leaf_step<LDS16, BLOCK>(Tb, p, T);
+            if (T.node < 0 && T.node != kLeafSentinel) leaf_step<LDS16, BLOCK>(Tb, p, T, S.t_scale);
             if (TIMING) cyc[3] += cycle_stamp() - t_leaf;
         }
     }
@@ -1767,6 +1767,13 @@ float descent_eps_rel(const rt_scene* sc, const rt_camera& c) {
         m = std::max(m, std::fabs(c.lookfrom[a] - double(sc->dev.qbase[a])) + std::fabs(c.aperture));
     }
     return float(2.0 * m * (1.0 / 1048576.0));  // 2^-20: the centre / half-extent form takes two more roundings per axis
+}
+
+// 1 / (a length no segment reaches): with m = the largest distance, on any axis, of a box plane or a path origin
+// from the reference point (descent_eps_rel's m = eps_rel * 2^19), two such points are at most 2 * sqrt(3) * m apart
+float descent_t_scale(float eps_rel) {
+    const double m = double(eps_rel) * 524288.0;
+    return float(1.0 / std::max(4.0 * m, 1.0e-30));
 }
 
 double camera_abs(const rt_camera& c) {
@@ -2281,6 +2288,7 @@ int launch_render(rt_scene* scene, const rt_camera* cam, const rt_render_opts* o
     SceneDev S = scene->dev;
     S.eps = descent_eps(scene, camera_abs(*cam));
     S.eps_rel = descent_eps_rel(scene, *cam);
+    S.t_scale = descent_t_scale(S.eps_rel);
     const CamDev C = make_cam(*cam);
     const uint64_t n_work = uint64_t(P.tiles_x) * P.tiles_y * 64u * P.n_chunks;
     // one render of a handle at a time on the device: they share the work counter and the partial sums
