@@ -79,6 +79,7 @@ struct SceneDev {
     const TexMatDev* texmat;
     const TexImgDev* teximg;
     int32_t n_nodes, n_spheres, n_discs;
+    uint32_t wide_same_centre;  // bit i: wide sphere i has the centre of wide sphere i - 1 (they follow one another in the tables)
     int32_t n_tree, n_wide; // n_spheres = n_tree + n_wide; a wide sphere's box covers most of the others, so every
                             // ray would reach its leaf anyway: it is tested once per segment before the descent
     float eps;              // origin widening for the f32 descent
@@ -751,6 +752,7 @@ constexpr int kSmallScene = 12;     // up to this many spheres no tree is built 
 constexpr int kInnerThreshold = 8;
 constexpr int kLeaveThreshold = 48;  // lanes that may leave the inner nodes before the wave turns to the leaves (measured flat from 40 up: with the short inner step a run is best ended by kInnerThreshold alone)
 
+constexpr uint32_t kQ1Offset = 12288;  // LDS bytes from a node's first half to its second (inner_loop_lds16): room for 768 nodes
 struct Node16 {       // 32 bytes: two 16-byte LDS reads
     uint16_t h[12];   // IEEE half bits; per axis x, y, z: centre of child 0, of child 1, half extent of child 0, of child 1
     int32_t child0, child1;
@@ -773,18 +775,32 @@ struct Trav {
 // sphere_intersect_f64 followed by consider() in one piece: the same operations in the same order (a negative
 // discriminant gives a NaN root, which fails both comparisons); the arithmetic runs for every lane, only the rare
 // comparisons are skipped.  Returns whether `best` changed.
-__device__ __forceinline__ bool sphere_candidate(const double4 s, int32_t k, int32_t id, const Path& p, bool enabled,
-                                                 Best& best) {
+// The test comes in two parts.  What depends on the sphere's CENTRE only (src/geometry.rs:105-107: oc, b, and the
+// oc . oc of c) is computed by sphere_centre_terms; spheres that share a centre (the shells of a hollow glass ball,
+// src/materials.rs:102-106 models glass by nesting them) share those values bit for bit, so the second and later
+// ones skip that part (15 of the test's 50 instructions).
+struct CentreTerms {
+    double b, bb, oc2;  // 2 oc . d, its square, oc . oc
+};
+__device__ __forceinline__ CentreTerms sphere_centre_terms(const double4 s, const Path& p) {
+#pragma clang fp contract(off)
+    const double rx = p.ox - s.x, ry = p.oy - s.y, rz = p.oz - s.z;
+    CentreTerms c;
+    c.b = 2.0 * (rx * p.dx + ry * p.dy + rz * p.dz);
+    c.oc2 = rx * rx + ry * ry + rz * rz;
+    c.bb = c.b * c.b;
+    return c;
+}
+__device__ __forceinline__ bool sphere_candidate_with(const CentreTerms ct, double radius, int32_t k, int32_t id, bool enabled,
+                                                      Best& best) {
     bool better;
     double t;
     {
 #pragma clang fp contract(off)
-        const double rx = p.ox - s.x, ry = p.oy - s.y, rz = p.oz - s.z;
-        const double b = 2.0 * (rx * p.dx + ry * p.dy + rz * p.dz);
-        const double c = (rx * rx + ry * ry + rz * rz) - s.w * s.w;
-        const double discrm = b * b - 4.0 * c;
+        const double c = ct.oc2 - radius * radius;
+        const double discrm = ct.bb - 4.0 * c;
         const double sq = sqrt_discriminant(discrm);
-        const double t_smaller = -0.5 * (b + sq);
+        const double t_smaller = -0.5 * (ct.b + sq);
         const double t_larger = t_smaller + sq;
         // short-circuit operators: the compiler skips the tie rule and the second root's test for waves in which no
         // lane needs them, which came out 100 instructions shorter over the kernel than the branch-free form
@@ -798,6 +814,10 @@ __device__ __forceinline__ bool sphere_candidate(const double4 s, int32_t k, int
     best.id = better ? id : best.id;
     return better;
 }
+__device__ __forceinline__ bool sphere_candidate(const double4 s, int32_t k, int32_t id, const Path& p, bool enabled,
+                                                 Best& best) {
+    return sphere_candidate_with(sphere_centre_terms(s, p), s.w, k, id, enabled, best);
+}
 
 // The render kernels' descent works in coordinates RELATIVE to a point of the scene (`base`), in units of `step`:
 // a stored value q stands for the coordinate base + q * step, and the affine map is folded into the per-ray factors:
@@ -810,7 +830,7 @@ __device__ __forceinline__ bool sphere_candidate(const double4 s, int32_t k, int
 // box, step = a power of two that brings the half extent to about 1024, inside f16's normal range whatever the
 // scene's scale).
 template <bool GRID>
-__device__ __forceinline__ void trav_begin(const SceneDev& S, const Tables& Tb, const Path& p, Trav& T, uint32_t slot1_addr) {
+__device__ __forceinline__ void trav_begin(const SceneDev& S, const Tables& Tb, const Path& p, Trav& T, uint32_t slot1_addr, int32_t root) {
     T.best.t = 0.0;
     T.best.k = -1;
     T.best.id = 0x7fffffff;
@@ -823,11 +843,14 @@ __device__ __forceinline__ void trav_begin(const SceneDev& S, const Tables& Tb, 
     }
     // a sphere parameter is always positive: nothing can beat a non-positive disc hit
     const bool spheres_matter = !(T.best.k >= 0 && T.best.t <= 0.0);
+    CentreTerms ct{0.0, 0.0, 0.0};
     for (int32_t i = 0; i < S.n_wide; ++i) {
         const int32_t k = S.n_tree + i;
-        sphere_candidate(Tb.sph[k], k, Tb.prim_id[k], p, spheres_matter, T.best);
+        const double4 s = Tb.sph[k];
+        if (!((S.wide_same_centre >> i) & 1u)) ct = sphere_centre_terms(s, p);  // wave-uniform: a fact of the scene
+        sphere_candidate_with(ct, s.w, k, Tb.prim_id[k], spheres_matter, T.best);
     }
-    T.node = (S.n_nodes == 0 || !spheres_matter) ? kLeafSentinel : 0;
+    T.node = (S.n_nodes == 0 || !spheres_matter) ? kLeafSentinel : root;
     const double o64[3] = {p.ox, p.oy, p.oz};
     const float df[3] = {float(p.dx), float(p.dy), float(p.dz)};
 #pragma unroll
@@ -895,13 +918,22 @@ __device__ __forceinline__ void descend(Trav& T, float en0, float ex0, float en1
     }
 }
 
+// LDS byte address of an object in dynamic shared memory
+__device__ __forceinline__ uint32_t lds_address(const void* p) {
+    return uint32_t(uintptr_t((__attribute__((address_space(3))) const void*)p));
+}
+
 template <bool LDS16, int BLOCK>
 __device__ __forceinline__ void inner_step(const SceneDev& S, const uint4* lds_q0, const uint4* lds_q1, Trav& T) {
     float en0, ex0, en1, ex1;
     int32_t c0, c1;
     // dwords: a.x = centres x (child 0 | child 1 << 16), a.y = half extents x, a.z / a.w = the same for y, b.x / b.y for z
     uint4 a, b;
-    if (LDS16) { a = lds_q0[T.node]; b = lds_q1[T.node]; }
+    if (LDS16) {  // an inner link of the staged tree is the LDS address of the node's first half
+        const uint32_t idx = (uint32_t(T.node) - lds_address(lds_q0)) >> 4;
+        a = lds_q0[idx];
+        b = lds_q1[idx];
+    }
     else { const uint4* q = reinterpret_cast<const uint4*>(S.nodes32 + T.node); a = q[0]; b = q[1]; }
     const uint32_t cw[3] = {a.x, a.z, b.x}, hw[3] = {a.y, a.w, b.y};
     float ce0[3], ce1[3], he0[3], he1[3];
@@ -920,30 +952,34 @@ __device__ __forceinline__ void inner_step(const SceneDev& S, const uint4* lds_q
     descend<BLOCK>(T, en0, ex0, en1, ex1, c0, c1);
 }
 
-// LDS byte address of an object in dynamic shared memory
-__device__ __forceinline__ uint32_t lds_address(const void* p) {
-    return uint32_t(uintptr_t((__attribute__((address_space(3))) const void*)p));
-}
 
 // The inner-node loop of the LDS-resident f16 tree, written out in gfx950 assembly:
 //     while (at least `thr` lanes of the wave stand on an inner node, or some do and none waits at a leaf)
 //         those lanes take one inner_step
 // It is the same arithmetic as slab2/descend above (f16 bounds fed to v_fma_mix_f32, the lane's stack column in
-// LDS with its top in a register).  What the compiler's version of this loop spends and this one does not: about
-// sixteen register copies per turn for the loop-carried values, and a wait for the popped stack entry before the
-// next node can be fetched.  Here every lane's next node is settled first (the selected child, or the stack top,
-// which is in a register), the exit test is made on it, and the next node's two reads are issued BEFORE the push /
-// pop bookkeeping, which runs while they are in flight; one taken branch per turn.
+// LDS with its top in a register).  Every instruction of a step costs about two SIMD cycles whatever its kind
+// (tools/microbench/inner_step.hip), so the loop is built for the fewest instructions:
+//   * an inner link IS the LDS byte address of the node's first half (the kernel adds the array's address to the
+//     links while it stages the nodes) and the second half sits kQ1Offset bytes behind it: a fetch is two ds_read_b128
+//     and no address arithmetic;
+//   * the entry parameters on z are formed with the clamp modifier (parameters are in units of SceneDev::t_scale, so
+//     [0, 1] covers every segment), which is max(., 0) for free;
+//   * the lane masks go straight into EXEC where they are needed once (s_and / s_andn2 with EXEC as destination);
+//   * the loop's back edge is the conditional branch of the "enough lanes left" test.
+// Per step: 2 reads + wait, 18 slab + 2 min + 4 max3 / min3, 3 compares + 3 scalar + 3 selects, 7 for the stack,
+// 7 for the test and the masks = 49 (round 2: 56).
 // Fixed registers: v112-v127 and s88-s99 are scratch of this block (the 128-bit node halves need named registers,
 // inline-asm operands cannot name the dwords of a tuple).  EXEC is narrowed inside and restored before leaving.
+#define RT_STR2(x) #x
+#define RT_STR(x) RT_STR2(x)
+#define RT_FETCH16 "ds_read_b128 v[120:123], %[node]\n\tds_read_b128 v[124:127], %[node] offset:" RT_STR(12288) "\n\t"
+static_assert(kQ1Offset == 12288, "RT_FETCH16 spells the offset out");
 template <int BLOCK>
-__device__ __forceinline__ void inner_loop_lds16(Trav& T, uint32_t q0_addr, uint32_t q1_addr, int32_t thr) {
+__device__ __forceinline__ void inner_loop_lds16(Trav& T, int32_t thr) {
     static_assert(BLOCK == 512 || BLOCK == 256, "stack column stride");
     // the "s" operands must BE scalar registers: the constraint alone does not move a value the compiler holds in a
     // vector register (it would print v13 into an s_ instruction)
     thr = __builtin_amdgcn_readfirstlane(max(thr, 1));  // with 0 the loop would never see "no lane left"
-    q0_addr = uint32_t(__builtin_amdgcn_readfirstlane(int32_t(q0_addr)));
-    q1_addr = uint32_t(__builtin_amdgcn_readfirstlane(int32_t(q1_addr)));
     int32_t lanes_on_inner;
     asm volatile(
         // which lanes stand on an inner node, and whether to run at all
@@ -959,10 +995,7 @@ __device__ __forceinline__ void inner_loop_lds16(Trav& T, uint32_t q0_addr, uint
         "s_cbranch_scc1 9f\n\t"
         "4:\n\t"
         "s_mov_b64 exec, vcc\n\t"
-        "v_lshl_add_u32 v112, %[node], 4, %[q0]\n\t"
-        "v_lshl_add_u32 v113, %[node], 4, %[q1]\n\t"
-        "ds_read_b128 v[120:123], v112\n\t"
-        "ds_read_b128 v[124:127], v113\n\t"
+        RT_FETCH16
         "1:\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
         // x: v120 = centres (child 0 | child 1), v121 = half extents
@@ -997,58 +1030,43 @@ __device__ __forceinline__ void inner_loop_lds16(Trav& T, uint32_t q0_addr, uint
         "v_cmp_le_f32_e64 s[90:91], v116, v112\n\t"   // h0
         "v_cmp_le_f32_e64 s[92:93], v117, v113\n\t"   // h1
         "v_cmp_lt_f32_e64 s[94:95], v117, v116\n\t"   // child 1 is entered first
-        "s_and_b64 s[96:97], s[90:91], s[92:93]\n\t"  // both
         "s_or_b64 s[98:99], s[90:91], s[92:93]\n\t"   // any
         "s_and_b64 s[94:95], s[94:95], s[92:93]\n\t"
         "s_andn2_b64 s[94:95], s[90:91], s[94:95]\n\t"  // go to c0: h0 and not (h1 and child 1 first)
-        "s_andn2_b64 s[98:99], exec, s[98:99]\n\t"      // none
-        "v_cndmask_b32_e64 %[node], v127, v126, s[94:95]\n\t"
+        "v_cndmask_b32_e64 v119, v127, v126, s[94:95]\n\t"
         "v_cndmask_b32_e64 v118, v126, v127, s[94:95]\n\t"  // the other child, pushed where both are hit
-        "v_cndmask_b32_e64 %[node], %[node], %[top], s[98:99]\n\t"  // no child hit: go on with the stack top
-        // every lane's next node is known: decide whether the loop goes on, and if so start the next fetch before
-        // the stack is brought up to date
+        "v_cndmask_b32_e64 %[node], %[top], v119, s[98:99]\n\t"  // no child hit: go on with the stack top
+        // the stack: lanes without a hit child pop, lanes with two push the other one
+        "s_andn2_b64 exec, exec, s[98:99]\n\t"
+        "v_subrev_u32_e32 %[sp], %[stride], %[sp]\n\t"
+        "ds_read_b32 %[top], %[sp]\n\t"
+        "s_and_b64 exec, s[90:91], s[92:93]\n\t"
+        "ds_write_b32 %[sp], %[top]\n\t"
+        "v_add_u32_e32 %[sp], %[stride], %[sp]\n\t"
+        "v_mov_b32_e32 %[top], v118\n\t"
+        // who goes on (lanes that left the loop earlier stand on a leaf or on the sentinel: negative either way)
+        "s_mov_b64 exec, s[88:89]\n\t"
         "v_cmp_lt_i32_e32 vcc, -1, %[node]\n\t"
         "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        RT_FETCH16
         "s_cmp_ge_i32 %[cnt], %[thr]\n\t"
-        "s_cbranch_scc0 5f\n\t"
-        "6:\n\t"
-        "s_mov_b64 exec, vcc\n\t"
-        "v_lshl_add_u32 v112, %[node], 4, %[q0]\n\t"
-        "v_lshl_add_u32 v113, %[node], 4, %[q1]\n\t"
-        "ds_read_b128 v[120:123], v112\n\t"
-        "ds_read_b128 v[124:127], v113\n\t"
-        "s_mov_b64 exec, s[96:97]\n\t"               // push
-        "ds_write_b32 %[sp], %[top]\n\t"
-        "v_add_u32_e32 %[sp], %[stride], %[sp]\n\t"
-        "v_mov_b32_e32 %[top], v118\n\t"
-        "s_mov_b64 exec, s[98:99]\n\t"               // pop
-        "v_subrev_u32_e32 %[sp], %[stride], %[sp]\n\t"
-        "ds_read_b32 %[top], %[sp]\n\t"
-        "s_mov_b64 exec, vcc\n\t"
-        "s_branch 1b\n\t"
-        "5:\n\t"  // fewer than `thr` lanes go on: leave when none does, or when some lane of the wave waits at a leaf
+        "s_cbranch_scc1 1b\n\t"
+        // fewer than `thr` lanes go on: leave when none does, or when some lane of the wave waits at a leaf
         "s_cmp_eq_u32 %[cnt], 0\n\t"
-        "s_cbranch_scc1 7f\n\t"
+        "s_cbranch_scc1 9f\n\t"
         "s_mov_b64 exec, s[88:89]\n\t"
         "v_cmp_lt_u32_e64 s[90:91], %[sentinel], %[node]\n\t"
+        "s_mov_b64 exec, vcc\n\t"
         "s_cmp_lg_u64 s[90:91], 0\n\t"
-        "s_cbranch_scc0 6b\n\t"
-        "7:\n\t"
-        "s_mov_b64 exec, s[96:97]\n\t"               // push
-        "ds_write_b32 %[sp], %[top]\n\t"
-        "v_add_u32_e32 %[sp], %[stride], %[sp]\n\t"
-        "v_mov_b32_e32 %[top], v118\n\t"
-        "s_mov_b64 exec, s[98:99]\n\t"               // pop
-        "v_subrev_u32_e32 %[sp], %[stride], %[sp]\n\t"
-        "ds_read_b32 %[top], %[sp]\n\t"
+        "s_cbranch_scc0 1b\n\t"
         "9:\n\t"
         "s_mov_b64 exec, s[88:89]\n\t"
         "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
         : [node] "+v"(T.node), [sp] "+v"(T.sp), [top] "+v"(T.top), [cnt] "=&s"(lanes_on_inner)
         : [ix] "v"(T.inv[0]), [iy] "v"(T.inv[1]), [iz] "v"(T.inv[2]), [ax] "v"(T.A[0]), [ay] "v"(T.A[1]),
           [az] "v"(T.A[2]), [ex] "v"(T.E[0]), [ey] "v"(T.E[1]), [ez] "v"(T.E[2]), [tmax] "v"(T.tmax),
-          [q0] "s"(q0_addr), [q1] "s"(q1_addr), [thr] "s"(thr), [sentinel] "s"(kLeafSentinel),
-          [stride] "s"(uint32_t(BLOCK * sizeof(int32_t)))
+          [thr] "s"(thr), [sentinel] "s"(kLeafSentinel), [stride] "s"(uint32_t(BLOCK * sizeof(int32_t)))
         : "memory", "vcc", "scc", "v112", "v113", "v114", "v115", "v116", "v117",
           "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "s88", "s89", "s90", "s91",
           "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
@@ -1212,10 +1230,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     extern __shared__ uint4 lds_raw[];
     // LDS layout (16-byte units): [q0: n_nodes][q1: n_nodes][spheres: 2*n_spheres][mat: n_prims]
     //                             [kind: n_prims/4][prim_id: n_prims/4][stack: stack_depth*BLOCK/4][hand-out state]
+    // (q1 begins kQ1Offset bytes after q0 whatever n_nodes is)
     const int32_t n_prims = S.n_spheres + S.n_discs, quads = (n_prims + 3) / 4;
     uint4* lds_q0 = lds_raw;
-    uint4* lds_q1 = lds_raw + (LDS16 ? S.n_nodes : 0);
-    uint4* lds_sph = lds_raw + (LDS16 ? 2 * S.n_nodes : 0);
+    uint4* lds_q1 = lds_raw + (LDS16 ? kQ1Offset / 16 : 0);  // second halves at a fixed distance from the first (see inner_loop_lds16)
+    uint4* lds_sph = lds_q1 + (LDS16 ? S.n_nodes : 0);
     uint4* lds_mat = lds_sph + (LDS16 ? 2 * S.n_spheres : 0);
     uint4* lds_kind = lds_mat + (LDS16 ? n_prims : 0);
     uint4* lds_id = lds_kind + (LDS16 ? quads : 0);
@@ -1229,7 +1248,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     lds_cam& Cl = *(lds_cam*)cam_slot;
     if (LDS16) {
         const uint4* src = reinterpret_cast<const uint4*>(nodes16);
-        for (int32_t i = threadIdx.x; i < S.n_nodes; i += BLOCK) { lds_q0[i] = src[2 * i]; lds_q1[i] = src[2 * i + 1]; }
+        // inner links arrive as 16 * node index and become LDS addresses here
+        const uint32_t q0_base = lds_address(lds_q0);
+        for (int32_t i = threadIdx.x; i < S.n_nodes; i += BLOCK) {
+            uint4 b = src[2 * i + 1];
+            if (int32_t(b.z) >= 0) b.z += q0_base;
+            if (int32_t(b.w) >= 0) b.w += q0_base;
+            lds_q0[i] = src[2 * i];
+            lds_q1[i] = b;
+        }
         const uint4* ssrc = reinterpret_cast<const uint4*>(S.sph);
         for (int32_t i = threadIdx.x; i < 2 * S.n_spheres; i += BLOCK) lds_sph[i] = ssrc[i];
         const uint4* msrc = reinterpret_cast<const uint4*>(S.mat);
@@ -1262,7 +1289,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     float ar = 0.0f, ag = 0.0f, ab = 0.0f;
     const int trav_threshold = int(P.trav_threshold), inner_threshold = int(P.inner_threshold);
     const int leave_threshold = int(P.leave_threshold);
-    const uint32_t q0_addr = lds_address(lds_q0), q1_addr = lds_address(lds_q1);
+    const uint32_t q0_addr = lds_address(lds_q0);
     const uint32_t slot1_addr = lds_address(stk) + uint32_t(BLOCK * sizeof(int32_t));
 
     for (;;) {
@@ -1340,7 +1367,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                     normalize3(d[0], d[1], d[2]);
                     p.ox = ox; p.oy = oy; p.oz = oz;
                     unit_f64(d[0], d[1], d[2], &p.dx, &p.dy, &p.dz);
-                    trav_begin<!LDS16>(S, Tb, p, T, slot1_addr);
+                    trav_begin<!LDS16>(S, Tb, p, T, slot1_addr, LDS16 ? int32_t(q0_addr) : 0);
                 }
             }
         }
@@ -1362,7 +1389,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
             const uint64_t t_inner = TIMING ? cycle_stamp() : 0;
             if (TIMING) cyc[1] += t_inner - t_head;
             if (LDS16 && !STATS) {
-                inner_loop_lds16<BLOCK>(T, q0_addr, q1_addr, run_threshold);
+                inner_loop_lds16<BLOCK>(T, run_threshold);
             } else if (!STATS) {
                 inner_loop_hbm<BLOCK>(T, S.nodes32, run_threshold);
             } else {
@@ -1945,6 +1972,25 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
         }
     }
     std::sort(wide_ids.begin(), wide_ids.end());
+    // wide spheres with the same centre next to one another (lowest ID first within a group, groups by their lowest ID):
+    // the render kernels compute the centre-dependent half of the sphere test once per group
+    uint32_t wide_same_centre = 0;
+    {
+        std::vector<uint32_t> grouped;
+        std::vector<char> used(wide_ids.size(), 0);
+        for (size_t i = 0; i < wide_ids.size(); ++i) {
+            if (used[i]) continue;
+            const double* ci = hittables[wide_ids[i]].centre;
+            for (size_t j = i; j < wide_ids.size(); ++j) {
+                const double* cj = hittables[wide_ids[j]].centre;
+                if (used[j] || cj[0] != ci[0] || cj[1] != ci[1] || cj[2] != ci[2]) continue;
+                if (j != i && grouped.size() < 32) wide_same_centre |= 1u << grouped.size();
+                used[j] = 1;
+                grouped.push_back(wide_ids[j]);
+            }
+        }
+        wide_ids.swap(grouped);
+    }
     // the assembly descent forms a node's byte offset (index * 32) in 32 bits
     if (tree_ids.size() > (size_t(1) << 26)) return bail(fail(RT_ERR_LIMIT, "rt_scene_create: more than 2^26 spheres in the tree"));
 
@@ -2084,8 +2130,9 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
     }
     {
         const size_t n_prims = n_s + n_d;
-        const size_t scene_bytes = 32 * n_nodes + 32 * n_s + 16 * n_prims + 2 * 16 * ((n_prims + 3) / 4);
-        if (n_s > 0 && !resident && lds16_launch_bytes(scene_bytes, sc->stack_depth) <= kLdsPerCu / 2) {
+        // node halves: the first array takes kQ1Offset bytes whatever it holds (see inner_loop_lds16)
+        const size_t scene_bytes = kQ1Offset + 16 * n_nodes + 32 * n_s + 16 * n_prims + 2 * 16 * ((n_prims + 3) / 4);
+        if (n_s > 0 && !resident && 16 * n_nodes <= kQ1Offset && lds16_launch_bytes(scene_bytes, sc->stack_depth) <= kLdsPerCu / 2) {
             std::vector<Node16> n16(bvh.nodes.size());
             auto rel = [&](float plane, int a) { return (double(plane) - double(sc->dev.hbase[a])) / double(sc->dev.hstep[a]); };  // exact
             // centre = the half float nearest to the box's middle, half extent = the smallest half float that still
@@ -2103,7 +2150,8 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
                     encode(nd.lo0[a], nd.hi0[a], a, &n16[i].h[4 * a], &n16[i].h[4 * a + 2]);
                     encode(nd.lo1[a], nd.hi1[a], a, &n16[i].h[4 * a + 1], &n16[i].h[4 * a + 3]);
                 }
-                n16[i].child0 = nd.child0; n16[i].child1 = nd.child1;
+                // an inner link is 16 * node index: the byte offset of the node's first half in the staged array
+            n16[i].child0 = nd.child0 >= 0 ? nd.child0 * 16 : nd.child0; n16[i].child1 = nd.child1 >= 0 ? nd.child1 * 16 : nd.child1;
             }
             if ((rc = upload(sc, n16, &sc->d_nodes16)) != RT_OK) return bail(rc);
             sc->lds16_scene_bytes = scene_bytes;
@@ -2214,6 +2262,7 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
     sc->dev.n_spheres = int32_t(n_s);
     sc->dev.n_tree = int32_t(n_tree);
     sc->dev.n_wide = int32_t(n_wide);
+    sc->dev.wide_same_centre = wide_same_centre;
     sc->dev.n_discs = int32_t(n_d);
     sc->dev.eps = 0.0f;
     sc->dev.eps_rel = 0.0f;

@@ -55,6 +55,69 @@ constexpr int kSteps = 4096;
     "v_max3_f32 v117, v117, v119, v123\n\t"                                                         \
     "v_min3_f32 v113, v113, v115, v125\n\t"
 
+#define SLAB_NEAR                                                                                      \
+    "v_fma_mix_f32 v112, v120, %[ix], %[ax] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"                   \
+    "v_fma_mix_f32 v113, v120, %[ix], %[ax] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"                   \
+    "v_fma_mix_f32 v114, v121, |%[ix]|, %[ex] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"                 \
+    "v_fma_mix_f32 v115, v121, |%[ix]|, %[ex] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"                 \
+    "v_pk_add_f32 v[116:117], v[112:113], v[114:115] neg_lo:[0,1] neg_hi:[0,1]\n\t"                 \
+    "v_pk_add_f32 v[112:113], v[112:113], v[114:115]\n\t"                                           \
+    "v_fma_mix_f32 v114, v122, %[iy], %[ay] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"                   \
+    "v_fma_mix_f32 v115, v122, %[iy], %[ay] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"                   \
+    "v_fma_mix_f32 v120, v123, |%[iy]|, %[ey] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"                 \
+    "v_fma_mix_f32 v121, v123, |%[iy]|, %[ey] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"                 \
+    "v_pk_add_f32 v[118:119], v[114:115], v[120:121] neg_lo:[0,1] neg_hi:[0,1]\n\t"                 \
+    "v_pk_add_f32 v[114:115], v[114:115], v[120:121]\n\t"                                           \
+    "v_fma_mix_f32 v120, v124, %[iz], %[az] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"                   \
+    "v_fma_mix_f32 v121, v124, %[iz], %[az] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"                   \
+    "v_fma_mix_f32 v122, v125, |%[iz]|, %[ez] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"                 \
+    "v_fma_mix_f32 v123, v125, |%[iz]|, %[ez] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"                 \
+    "v_pk_add_f32 v[124:125], v[120:121], v[122:123]\n\t"                                           \
+    "v_pk_add_f32 v[122:123], v[120:121], v[122:123] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"           \
+    "v_min_f32_e32 v124, v124, %[tmax]\n\t"                                                         \
+    "v_min_f32_e32 v125, v125, %[tmax]\n\t"                                                         \
+    "v_max3_f32 v116, v116, v118, v122\n\t"                                                         \
+    "v_min3_f32 v112, v112, v114, v124\n\t"                                                         \
+    "v_max3_f32 v117, v117, v119, v123\n\t"                                                         \
+    "v_min3_f32 v113, v113, v115, v125\n\t"
+
+
+// variants 9 / 10: the step after the restructuring.  The masks are used where they are made (s_and / s_andn2 write
+// EXEC directly), the stack is brought up to date BEFORE the next fetch (9) or after it (10, which has to keep the old
+// EXEC in s[84:85]), the second half of a node is read at a constant offset from the first (one address computation),
+// and the loop's back edge is the conditional branch of the exit test.
+#define SELECT_ANY                                                                                \
+    "v_cmp_le_f32_e64 s[90:91], v116, v112\n\t"                                                     \
+    "v_cmp_le_f32_e64 s[92:93], v117, v113\n\t"                                                     \
+    "v_cmp_lt_f32_e64 s[94:95], v117, v116\n\t"                                                     \
+    "s_or_b64 s[98:99], s[90:91], s[92:93]\n\t"                                                     \
+    "s_and_b64 s[94:95], s[94:95], s[92:93]\n\t"                                                    \
+    "s_andn2_b64 s[94:95], s[90:91], s[94:95]\n\t"                                                  \
+    "v_cndmask_b32_e64 v119, v127, v126, s[94:95]\n\t"                                              \
+    "v_cndmask_b32_e64 v118, v126, v127, s[94:95]\n\t"                                              \
+    "v_cndmask_b32_e64 %[node], %[top], v119, s[98:99]\n\t"
+#define STACK_FIRST                                                                               \
+    "s_andn2_b64 exec, exec, s[98:99]\n\t"                                                          \
+    "v_subrev_u32_e32 %[sp], %[stride], %[sp]\n\t"                                                  \
+    "ds_read_b32 %[top], %[sp]\n\t"                                                                 \
+    "s_and_b64 exec, s[90:91], s[92:93]\n\t"                                                        \
+    "ds_write_b32 %[sp], %[top]\n\t"                                                                \
+    "v_add_u32_e32 %[sp], %[stride], %[sp]\n\t"                                                     \
+    "v_mov_b32_e32 %[top], v118\n\t"
+#define TEST_FETCH_LOOP                                                                           \
+    "s_mov_b64 exec, s[88:89]\n\t"                                                                  \
+    "v_cmp_lt_i32_e32 vcc, -1, %[node]\n\t"                                                         \
+    "s_bcnt1_i32_b64 s87, vcc\n\t"                                                                  \
+    "s_mov_b64 exec, vcc\n\t"                                                                       \
+    "v_lshl_add_u32 v112, %[node], 4, %[q0]\n\t"                                                    \
+    "ds_read_b128 v[120:123], v112\n\t"                                                             \
+    "ds_read_b128 v[124:127], v112 offset:8192\n\t"                                                 \
+    "s_sub_u32 s86, s86, 1\n\t"                                                                     \
+    "s_cmp_ge_i32 s87, %[thr]\n\t"                                                                  \
+    "s_cbranch_scc0 5f\n\t"                                                                         \
+    "s_cmp_lg_u32 s86, 0\n\t"                                                                       \
+    "s_cbranch_scc1 1b\n\t"                                                                         \
+    "5:\n\ts_mov_b64 exec, s[88:89]\n\ts_waitcnt lgkmcnt(0)\n\t"
 // variant 6: z additions with clamp (parameters normalised to [0, 1]), no v_max / v_min
 #define SLAB_CLAMP                                                                                \
     "v_fma_mix_f32 v112, v120, %[ix], %[ax] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"                   \
@@ -306,6 +369,10 @@ __global__ void k_inner(unsigned long long* out, const uint4* tree, float seed, 
     if (VARIANT == 6) asm volatile(HEAD SLAB_CLAMP SELECT_SCALAR EXIT_TEST FETCH PUSH_POP COUNT OPERANDS);
     if (VARIANT == 7) asm volatile(HEAD SLAB_DOT2 SELECT_SCALAR EXIT_TEST FETCH PUSH_POP COUNT OPERANDS);
     if (VARIANT == 8) asm volatile(HEAD4 SLAB4 SELECT4 EXIT_TEST PUSH_POP4 FETCH4 COUNT OPERANDS4);
+    if (VARIANT == 9) asm volatile(HEAD SLAB_NEAR SELECT_SCALAR EXIT_TEST FETCH PUSH_POP COUNT OPERANDS);
+    if (VARIANT == 10)
+        asm volatile("s_mov_b64 s[88:89], exec\n\ts_mov_b32 s86, %[n]\n\tv_lshl_add_u32 v112, %[node], 4, %[q0]\n\tds_read_b128 v[120:123], v112\n\t"
+                     "ds_read_b128 v[124:127], v112 offset:8192\n\t1:\n\ts_waitcnt lgkmcnt(0)\n\t" SLAB_NEAR SELECT_ANY STACK_FIRST TEST_FETCH_LOOP OPERANDS);
     if (VARIANT == 5)
         asm volatile("s_mov_b64 s[88:89], exec\n\ts_mov_b32 s86, %[n]\n\t" FETCH_SIDE_BY_SIDE "1:\n\ts_waitcnt lgkmcnt(0)\n\t" SLAB SELECT_SCALAR EXIT_TEST
                          FETCH_SIDE_BY_SIDE PUSH_POP COUNT OPERANDS);
@@ -371,14 +438,14 @@ int main() {
     CHECK(hipMalloc(&d_tree_c, tree_c.size() * 4));
     CHECK(hipMemcpy(d_tree_c, tree_c.data(), tree_c.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMalloc(&d_out, 16 + 1024 * 8));
-    const char* names[9] = {"loop as run (round 2)", "no exit test", "no push/pop", "vector select", "scalar logic spread", "node halves side by side",
-                            "clamp for v_max/v_min", "dot2 + clamp", "4-child node, dot2"};
-    const int boxes[9] = {2, 2, 2, 2, 2, 2, 2, 2, 4};
+    const char* names[11] = {"loop as run (round 2)", "no exit test", "no push/pop", "vector select", "scalar logic spread", "node halves side by side",
+                            "clamp for v_max/v_min", "dot2 + clamp", "4-child node, dot2", "loop as run (round 3a)", "restructured"};
+    const int boxes[11] = {2, 2, 2, 2, 2, 2, 2, 2, 4, 2, 2};
     std::printf("%-24s %14s %14s %14s %16s   (SIMD cycles per step of one wave, 64 lanes on)\n", "variant", "1 wave/SIMD", "2 waves/SIMD",
                 "4 waves/SIMD", "per box, 4 w/SIMD");
     for (int coherent = 0; coherent < 2; ++coherent) {
     std::printf("-- %s\n", coherent ? "every lane of a wave on the same node (broadcast reads)" : "every lane on a node of its own (random 16-byte slots)");
-    for (int v = 0; v < 9; ++v) {
+    for (int v = 0; v < 11; ++v) {
         double cyc[3];
         int slot = 0;
         for (int threads : {256, 512, 1024}) {
@@ -393,6 +460,8 @@ int main() {
                 case 5: hipLaunchKernelGGL(k_inner<5>, dim3(n_cu), dim3(threads), lds_bytes, 0, d_out, d_tree, 1.5f, coherent); break;
                 case 6: hipLaunchKernelGGL(k_inner<6>, dim3(n_cu), dim3(threads), lds_bytes, 0, d_out, d_tree, 1.5f, coherent); break;
                 case 7: hipLaunchKernelGGL(k_inner<7>, dim3(n_cu), dim3(threads), lds_bytes, 0, d_out, d_tree_b, 1.5f, coherent); break;
+                case 9: hipLaunchKernelGGL(k_inner<9>, dim3(n_cu), dim3(threads), lds_bytes, 0, d_out, d_tree, 1.5f, coherent); break;
+                case 10: hipLaunchKernelGGL(k_inner<10>, dim3(n_cu), dim3(threads), lds_bytes, 0, d_out, d_tree, 1.5f, coherent); break;
                 default: hipLaunchKernelGGL(k_inner<8>, dim3(n_cu), dim3(threads), lds_bytes, 0, d_out, d_tree_c, 1.5f, coherent); break;
             }
             CHECK(hipDeviceSynchronize());
