@@ -7,6 +7,11 @@
 A step = one render of the random-spheres scene (488 spheres, seed 1) at 1920x1080, 100 samples per
 pixel per GPU, depth 50: rank g traces samples [100g, 100(g+1)) of every pixel, the float sum images
 are reduced to rank 0 over RCCL, rank 0 applies mean/gamma/quantise.  Prints ONE JSON line on rank 0.
+
+    python bench.py --config c3 [--gpus N] [--spp S]
+
+is the 8-GPU configuration of the same scene as a STRONG-scaling run: 3840x2160, S (default 1000) samples
+per pixel in total, rank g traces sample_shard(S, g, N); same JSON line with "scaling": "strong".
 """
 import argparse
 import json
@@ -18,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 
 WIDTH, HEIGHT, SPP_PER_GPU, DEPTH, SCENE_SEED, SEED = 1920, 1080, 100, 50, 1, 0
+C3_WIDTH, C3_HEIGHT, C3_SPP_TOTAL = 3840, 2160, 1000
 
 
 def cpu_baseline(hittables, budget_s):
@@ -62,7 +68,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--kernel-flags", type=int, default=0, help="RT_RENDER_KERNEL_* measurement aids (A/B runs)")
+    ap.add_argument("--config", default="c2", choices=["c2", "c3"],
+                    help="c2: 1920x1080, 100 spp per GPU (weak scaling, the headline); c3: 3840x2160, 1000 spp in total split over the GPUs (strong scaling)")
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel: per GPU for c2, in total for c3 (0 = the configuration's own)")
     args = ap.parse_args()
+    global WIDTH, HEIGHT
+    strong = args.config == "c3"
+    if strong:
+        WIDTH, HEIGHT = C3_WIDTH, C3_HEIGHT
 
     import torch
     import torch.distributed as dist
@@ -94,7 +107,9 @@ def main():
     n_pixels = WIDTH * HEIGHT
     d_sum = torch.zeros(HEIGHT, WIDTH, 3, dtype=torch.float32, device="cuda")
     d_rgb = torch.zeros(HEIGHT, WIDTH, 3, dtype=torch.uint8, device="cuda")
-    total_spp = SPP_PER_GPU * world
+    total_spp = (args.spp or C3_SPP_TOTAL) if strong else (args.spp or SPP_PER_GPU) * world
+    if total_spp < world:
+        raise SystemExit("bench.py: %d samples for %d GPUs" % (total_spp, world))
     begin, end = rt.sample_shard(total_spp, rank, world)
     kernel_ms = []
 
@@ -161,20 +176,25 @@ def main():
         seg = round((float(st[5]) - float(st[6])) / (n_pixels * (end - begin)), 4)
         base = cpu_baseline(hittables, args.cpu_seconds) if (args.cpu_seconds > 0 and world == 1) else None
         fpp = roofline.flops_per_path(len(hittables), seg)
-        traffic = roofline.measured_traffic_bytes()
+        # HBM bytes per launch come from the committed counter passes over exactly this command line (one GPU, the
+        # headline configuration, no measurement flags); any other run reports null
+        profiled_run = world == 1 and not strong and not args.spp and args.kernel_flags == 0
+        traffic = roofline.measured_traffic_bytes() if profiled_run else None
         achieved = (n_pixels * (end - begin)) * fpp / (render_ms * 1e-3) / 1e12 if render_ms > 0 else 0.0
         img_mean = float(d_rgb.float().mean().item())
         line = {
-            "metric": "Mpaths/sec at 1920x1080 random-spheres", "value": round(value, 3), "unit": "Mpaths/s",
+            "metric": "Mpaths/sec at %dx%d random-spheres" % (WIDTH, HEIGHT), "value": round(value, 3), "unit": "Mpaths/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not rehearse else "synthetic; REHEARSAL on shared GPUs over gloo, not a measurement",
-            "config": {"workload": "random-spheres 488 spheres (seed 1), 1920x1080, %d spp per GPU (%d total), depth %d"
-                                   % (SPP_PER_GPU, total_spp, DEPTH),
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not rehearse else "synthetic; REHEARSAL on shared GPUs over gloo, not a measurement",
+            "config": {"workload": "random-spheres 488 spheres (seed 1), %dx%d, %s, depth %d"
+                                   % (WIDTH, HEIGHT, ("%d spp in total split over the GPUs" % total_spp) if strong
+                                      else "%d spp per GPU (%d total)" % (total_spp // world, total_spp), DEPTH),
                        "paths_per_step": paths_per_step, "parallelism": "sample-split x%d + RCCL sum-reduce" % world,
                        "image_mean_u8": round(img_mean, 3)},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": roofline.PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / roofline.PEAK_FP32_TFLOPS, 5),
-                         "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_source": traffic["source"] if traffic else None,
+                         "traffic": traffic["bytes_per_launch"] if traffic else None,
+                         "traffic_source": traffic["source"] if traffic else "not collected for this command line (the committed counter passes cover `bench.py` on one GPU)",
                          "kernel": "render_kernel_ws<true, 512, 0> (+ combine_kernel, 0.03 ms)", "kernel_ms": round(render_ms, 3),
                          "kernel_ms_source": "HIP events on the launching stream around rt_render_device, mean of the timed steps",
                          "algorithmic_flops_per_path": round(fpp, 1), "segments_per_path": seg,

@@ -182,6 +182,11 @@ int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_render_opts
 /* Sizes the scene's partial-sum buffer for renders of this frame and sample range (and anything smaller), so that
  * rt_render_device neither allocates nor waits.  No counterpart in the reference (it has no device). */
 int rt_scene_reserve(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts);
+/* Upper bound of that buffer: when the library chooses the chunking (samples_per_item = 0) a render is cut into at
+ * most RT_PARTIALS_BUDGET_BYTES / (horiz_res * vert_res * 12) chunks (and never more than 64), so the partial sums of
+ * any frame stay within this budget (a 3840x2160 frame: 10 chunks; chunks grow longer instead).  A chunking given
+ * by the caller is taken as it is. */
+#define RT_PARTIALS_BUDGET_BYTES (1024u * 1024u * 1024u)
 
 /* rt_render_device for callers that cannot allocate device memory (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same result; the

@@ -1736,7 +1736,15 @@ int check_render_args(const rt_scene* scene, const rt_camera* cam, const rt_rend
 }
 
 // tree_in_hbm: the render kernel will gather its nodes from memory (see chunk rule below)
-RenderParams make_params(const rt_camera& cam, const rt_render_opts& o, bool tree_in_hbm, uint32_t max_chunks = 64) {
+// Most chunks a render of this frame may be cut into: the partial sums (one frame-sized slot per chunk) stay within
+// RT_PARTIALS_BUDGET_BYTES, and never more than 64 slots
+uint32_t chunk_cap(const rt_camera& cam) {
+    const uint64_t slot = uint64_t(cam.horiz_res) * cam.vert_res * 3 * sizeof(float);
+    return uint32_t(std::min<uint64_t>(64, std::max<uint64_t>(1, uint64_t(RT_PARTIALS_BUDGET_BYTES) / std::max<uint64_t>(slot, 1))));
+}
+
+RenderParams make_params(const rt_camera& cam, const rt_render_opts& o, bool tree_in_hbm, uint32_t max_chunks = 0) {
+    if (max_chunks == 0) max_chunks = chunk_cap(cam);
     RenderParams P;
     P.sample_begin = o.sample_begin;
     P.sample_end = o.sample_end;
@@ -2340,8 +2348,14 @@ int launch_render(rt_scene* scene, const rt_camera* cam, const rt_render_opts* o
     S.t_scale = descent_t_scale(S.eps_rel);
     const CamDev C = make_cam(*cam);
     const uint64_t n_work = uint64_t(P.tiles_x) * P.tiles_y * 64u * P.n_chunks;
-    // one render of a handle at a time on the device: they share the work counter and the partial sums
-    RT_HIP(hipStreamWaitEvent(st, scene->ev_done, 0));
+    // one render of a handle at a time on the device: they share the work counter and the partial sums.  A stream
+    // that is being captured into a graph takes neither the wait nor the record: the event would become part of the
+    // capture, and the graph's own order (its nodes follow one another on the captured stream) stands in for it;
+    // keeping replays of the graph apart from other renders of the same handle is then the caller's business.
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (st && hipStreamIsCapturing(st, &capture) != hipSuccess) { (void)hipGetLastError(); capture = hipStreamCaptureStatusNone; }
+    const bool capturing = capture == hipStreamCaptureStatusActive;
+    if (!capturing) RT_HIP(hipStreamWaitEvent(st, scene->ev_done, 0));
     RT_HIP(hipMemsetAsync(d_work_counter, 0, kCounterBlockBytes, st));
     auto grid_for = [&](int per_cu, int block) {
         uint64_t blocks = uint64_t(scene->n_cu) * uint64_t(per_cu < 1 ? 1 : per_cu);
@@ -2374,7 +2388,7 @@ int launch_render(rt_scene* scene, const rt_camera* cam, const rt_render_opts* o
                            uint32_t(opts->flags & RT_RENDER_ACCUMULATE), d_sum_rgb);
         RT_HIP(hipGetLastError());
     }
-    RT_HIP(hipEventRecord(scene->ev_done, st));
+    if (!capturing) RT_HIP(hipEventRecord(scene->ev_done, st));
     return RT_OK;
 }
 

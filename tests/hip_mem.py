@@ -19,6 +19,12 @@ def hip():
         _hip.hipStreamDestroy.argtypes = [C.c_void_p]
         _hip.hipStreamQuery.argtypes = [C.c_void_p]
         _hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        _hip.hipStreamBeginCapture.argtypes = [C.c_void_p, C.c_int]
+        _hip.hipStreamEndCapture.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        _hip.hipGraphInstantiate.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        _hip.hipGraphLaunch.argtypes = [C.c_void_p, C.c_void_p]
+        _hip.hipGraphExecDestroy.argtypes = [C.c_void_p]
+        _hip.hipGraphDestroy.argtypes = [C.c_void_p]
     return _hip
 
 
@@ -55,6 +61,33 @@ class DeviceArray:
             self.ptr = C.c_void_p()
 
     __del__ = free
+
+
+class Graph:
+    """What was enqueued on `stream` between begin() and end(), as an executable HIP graph."""
+
+    def __init__(self, stream):
+        self.stream, self.graph, self.exe = stream, C.c_void_p(), C.c_void_p()
+
+    def begin(self):
+        check(hip().hipStreamBeginCapture(self.stream.handle, 0), "hipStreamBeginCapture")  # 0 = global mode
+
+    def end(self):
+        check(hip().hipStreamEndCapture(self.stream.handle, C.byref(self.graph)), "hipStreamEndCapture")
+        check(hip().hipGraphInstantiate(C.byref(self.exe), self.graph, None, None, C.c_size_t(0)), "hipGraphInstantiate")
+
+    def launch(self):
+        check(hip().hipGraphLaunch(self.exe, self.stream.handle), "hipGraphLaunch")
+
+    def close(self):
+        if self.exe:
+            hip().hipGraphExecDestroy(self.exe)
+            self.exe = C.c_void_p()
+        if self.graph:
+            hip().hipGraphDestroy(self.graph)
+            self.graph = C.c_void_p()
+
+    __del__ = close
 
 
 class Stream:

@@ -59,3 +59,31 @@ def test_two_rank_step_gives_the_single_render(rt):
     _, q = scene.render(rt.default_camera(1920, 1080), 200, depth=50, seed=0, want_sum=False)
     # two 100-sample sums added instead of one 200-sample sum: f32 rounding may move a channel by one step
     assert abs(d["config"]["image_mean_u8"] - float(np.mean(q))) < 0.01
+
+
+@pytest.mark.gpu
+def test_two_rank_strong_scaling_step_of_the_4k_configuration(rt):
+    """bench.py --config c3 --gpus 2 (3840x2160, the samples of ONE render split over the ranks), at a reduced sample
+    count and as a rehearsal on the GPUs that are there: "scaling" is strong, the paths of a step do not grow with the
+    ranks, and the finalised image is the single render's."""
+    import socket
+
+    import numpy as np
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--config", "c3", "--spp", "7"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["paths_per_step"] == 3840 * 2160 * 7
+    assert d["roofline"]["traffic"] is None
+    scene = rt.Scene(rt.gen_scene(1))
+    _, q = scene.render(rt.default_camera(3840, 2160), 7, depth=50, seed=0, want_sum=False)
+    assert abs(d["config"]["image_mean_u8"] - float(np.mean(q))) < 0.01

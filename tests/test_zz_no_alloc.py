@@ -59,3 +59,46 @@ def test_noalloc_render_equals_render_device_twice_in_a_row(rt):
     st_a, a = _render(lib.rt_render_device_noalloc, scene, cam, 6, 50, 8, 2, rt, stream=s2.handle)
     st_b, b = _render(lib.rt_render_device, scene, cam, 6, 50, 8, 2, rt)
     assert st_a == 0 and np.array_equal(a, b)
+
+
+def test_noalloc_render_leaves_free_memory_alone_and_replays_from_a_graph(rt):
+    """The two kinds of caller the entry point is for.  A serving loop: after one warm-up call (which asks the
+    scratch array's address and loads the code object) further calls leave the device's free memory exactly as it was.
+    Code under HIP graph capture: the call is captured on a stream of the caller's, and two replays of the graph
+    give the image of the plain render."""
+    import hip_mem
+
+    from raytracer_amd import _abi
+
+    lib = _abi.lib
+    scene = rt.Scene(rt.gen_scene(1))
+    cam = rt.default_camera(640, 360)
+    spp, spi = 12, 4  # three chunks: partial sums and the combine kernel are part of the call
+    o = rt.Scene.opts(0, spp, 50, 6, 0, spi)
+    out = hip_mem.DeviceArray(640 * 360 * 3)
+    stream = hip_mem.Stream()
+    assert lib.rt_render_device_noalloc(scene.handle, C.byref(cam.c), C.byref(o), out.ptr, stream.handle) == 0, lib.rt_last_error()
+    stream.synchronize()
+    want = out.numpy().copy()
+    free0 = hip_mem.mem_free()
+    for _ in range(3):
+        assert lib.rt_render_device_noalloc(scene.handle, C.byref(cam.c), C.byref(o), out.ptr, stream.handle) == 0
+    stream.synchronize()
+    assert hip_mem.mem_free() == free0
+    st_b, plain = _render(lib.rt_render_device, scene, cam, spp, 50, 6, spi, rt)
+    assert st_b == 0 and np.array_equal(want.reshape(360, 640, 3), plain)
+    # capture one call, replay it twice into a buffer wiped in between
+    g = hip_mem.Graph(stream)
+    g.begin()
+    status = lib.rt_render_device_noalloc(scene.handle, C.byref(cam.c), C.byref(o), out.ptr, stream.handle)
+    g.end()
+    assert status == 0, lib.rt_last_error()
+    for _ in range(2):
+        hip_mem.check(hip_mem.hip().hipMemset(out.ptr, 0xff, out.n * 4), "hipMemset")
+        g.launch()
+        stream.synchronize()
+        assert np.array_equal(out.numpy(), want)
+    g.close()
+    # and the handle still renders the ordinary way afterwards
+    st_c, again = _render(lib.rt_render_device, scene, cam, spp, 50, 6, spi, rt)
+    assert st_c == 0 and np.array_equal(again, plain)
