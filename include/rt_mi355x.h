@@ -116,7 +116,8 @@ enum {
     RT_RENDER_KERNEL_LOCKSTEP = 2,     /* measurement aid: the plain one-segment-per-turn kernel */
     RT_RENDER_KERNEL_NO_LDS_SCENE = 4, /* measurement aid: keep the BVH in HBM even when it would fit in LDS */
     RT_RENDER_STATS = 8,               /* measurement aid: instrumented kernel, see rt_debug_render_stats */
-    RT_RENDER_TIMING = 16              /* measurement aid: production kernel with a cycle stamp around each phase */
+    RT_RENDER_TIMING = 16,             /* measurement aid: production kernel with a cycle stamp around each phase */
+    RT_RENDER_DEFER_LEAF = 32          /* measurement aid, with RT_RENDER_STATS: a lane puts its first leaf off and descends on */
 };
 
 const char* rt_last_error(void);
