@@ -5,7 +5,9 @@
 // differs from the host one (no surface-area heuristic), the nearest hit of a ray does not: it is
 // the same argmin over the spheres whose boxes the conservative descent reaches.
 //
-//   1. 30-bit Morton code of every centre (10 bits per axis inside the box around all centres)
+//   1. 63-bit Morton code of every centre: 21 bits per axis on ONE cubic grid over the box around all centres (the
+//      same cell size on every axis: a flat scene then spends no splits on its thin axis until the cells get that
+//      small, where a grid normalised per axis would cut it into slabs)
 //   2. radix sort of (code, sphere index) — hipCUB, stable, so equal codes keep index order
 //   3. one thread per inner node finds its range and split by common-prefix lengths of neighbouring
 //      keys (key = code then position, so duplicates still split) and records the parent links
@@ -35,37 +37,40 @@ namespace {
         if (e_ != hipSuccess) { rc = fail(RT_ERR_DEVICE, "%s: %s", #call, hipGetErrorString(e_)); goto done; } \
     } while (0)
 
-__device__ __forceinline__ uint32_t spread10(uint32_t v) {  // 10 bits -> every third bit
-    v = (v * 0x00010001u) & 0xFF0000FFu;
-    v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u;
-    v = (v * 0x00000005u) & 0x49249249u;
-    return v;
+typedef unsigned long long key_t;
+__device__ __forceinline__ key_t spread21(uint32_t v) {  // 21 bits -> every third bit of 63
+    key_t x = v & 0x1fffffu;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
 }
 
-__global__ void morton_kernel(const double4* __restrict__ sph, uint32_t n, double3 lo, double3 inv_extent,
-                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+// inv_cell = 2^21 / (the largest extent of the box around the centres): one cubic grid for all three axes
+__global__ void morton_kernel(const double4* __restrict__ sph, uint32_t n, double3 lo, double inv_cell,
+                              key_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double4 s = sph[i];
-    const double fx = (s.x - lo.x) * inv_extent.x, fy = (s.y - lo.y) * inv_extent.y, fz = (s.z - lo.z) * inv_extent.z;
-    const uint32_t x = uint32_t(fmin(fmax(fx * 1024.0, 0.0), 1023.0));
-    const uint32_t y = uint32_t(fmin(fmax(fy * 1024.0, 0.0), 1023.0));
-    const uint32_t z = uint32_t(fmin(fmax(fz * 1024.0, 0.0), 1023.0));
-    keys[i] = (spread10(x) << 2) | (spread10(y) << 1) | spread10(z);
+    const uint32_t x = uint32_t(fmin(fmax((s.x - lo.x) * inv_cell, 0.0), 2097151.0));
+    const uint32_t y = uint32_t(fmin(fmax((s.y - lo.y) * inv_cell, 0.0), 2097151.0));
+    const uint32_t z = uint32_t(fmin(fmax((s.z - lo.z) * inv_cell, 0.0), 2097151.0));
+    keys[i] = (spread21(x) << 2) | (spread21(y) << 1) | spread21(z);
     vals[i] = i;
 }
 
 // length of the common prefix of keys i and j (code first, then position); -1 outside the array
-__device__ __forceinline__ int prefix(const uint32_t* __restrict__ keys, int n, int i, int j) {
+__device__ __forceinline__ int prefix(const key_t* __restrict__ keys, int n, int i, int j) {
     if (j < 0 || j >= n) return -1;
-    const uint32_t a = keys[i], b = keys[j];
-    if (a != b) return __clz(a ^ b);
-    return 32 + __clz(uint32_t(i) ^ uint32_t(j));
+    const key_t a = keys[i], b = keys[j];
+    if (a != b) return __clzll((long long)(a ^ b));
+    return 64 + __clz(uint32_t(i) ^ uint32_t(j));
 }
 
 // Inner node i of n - 1 (node 0 is the root); leaves are coded ~position as in Node.
-__global__ void hierarchy_kernel(const uint32_t* __restrict__ keys, int n, Node* __restrict__ nodes,
+__global__ void hierarchy_kernel(const key_t* __restrict__ keys, int n, Node* __restrict__ nodes,
                                  int32_t* __restrict__ parent_of_inner, int32_t* __restrict__ parent_of_leaf,
                                  int32_t* __restrict__ first_leaf) {
     const int i = int(blockIdx.x * blockDim.x + threadIdx.x);
@@ -157,18 +162,19 @@ int lbvh_on_device(const double4* d_sph, size_t n, const double clo[3], const do
     *nodes_out = nullptr;
     *order_out = nullptr;
     const double3 lo = make_double3(clo[0], clo[1], clo[2]);
-    auto inv = [](double e) { return e > 0.0 ? 1.0 / e : 0.0; };
-    const double3 inv_extent = make_double3(inv(chi[0] - clo[0]), inv(chi[1] - clo[1]), inv(chi[2] - clo[2]));
+    const double extent = std::max(std::max(chi[0] - clo[0], chi[1] - clo[1]), chi[2] - clo[2]);
+    const double inv_cell = extent > 0.0 ? 2097152.0 / extent : 0.0;
     int rc = RT_OK;
     const int ni = int(n);
-    uint32_t *d_keys = nullptr, *d_keys2 = nullptr, *d_vals = nullptr, *d_vals2 = nullptr, *d_arrived = nullptr;
+    key_t *d_keys = nullptr, *d_keys2 = nullptr;
+    uint32_t *d_vals = nullptr, *d_vals2 = nullptr, *d_arrived = nullptr;
     int32_t *d_pin = nullptr, *d_pleaf = nullptr, *d_first = nullptr;
     Node *d_nodes = nullptr, *d_nodes_dfs = nullptr;
     void* d_tmp = nullptr;
     size_t tmp_bytes = 0;
     const uint32_t block = 256, grid_n = uint32_t((n + block - 1) / block), grid_i = uint32_t((n - 1 + block - 1) / block);
     {
-        LBVH_HIP(hipMalloc(&d_keys, n * 4)); LBVH_HIP(hipMalloc(&d_keys2, n * 4));
+        LBVH_HIP(hipMalloc(&d_keys, n * sizeof(key_t))); LBVH_HIP(hipMalloc(&d_keys2, n * sizeof(key_t)));
         LBVH_HIP(hipMalloc(&d_vals, n * 4)); LBVH_HIP(hipMalloc(&d_vals2, n * 4));
         LBVH_HIP(hipMalloc(&d_pin, n * 4)); LBVH_HIP(hipMalloc(&d_pleaf, n * 4));
         LBVH_HIP(hipMalloc(&d_arrived, n * 4));
@@ -177,11 +183,11 @@ int lbvh_on_device(const double4* d_sph, size_t n, const double clo[3], const do
         LBVH_HIP(hipMalloc(&d_first, n * 4));
         LBVH_HIP(hipMemsetAsync(d_arrived, 0, n * 4, nullptr));
         LBVH_HIP(hipMemsetAsync(d_nodes, 0, (n - 1) * sizeof(Node), nullptr));
-        hipLaunchKernelGGL(morton_kernel, dim3(grid_n), dim3(block), 0, nullptr, d_sph, uint32_t(n), lo, inv_extent, d_keys, d_vals);
+        hipLaunchKernelGGL(morton_kernel, dim3(grid_n), dim3(block), 0, nullptr, d_sph, uint32_t(n), lo, inv_cell, d_keys, d_vals);
         LBVH_HIP(hipGetLastError());
-        LBVH_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys, d_keys2, d_vals, d_vals2, ni, 0, 30, nullptr));
+        LBVH_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys, d_keys2, d_vals, d_vals2, ni, 0, 63, nullptr));
         LBVH_HIP(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
-        LBVH_HIP(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_keys, d_keys2, d_vals, d_vals2, ni, 0, 30, nullptr));
+        LBVH_HIP(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_keys, d_keys2, d_vals, d_vals2, ni, 0, 63, nullptr));
         hipLaunchKernelGGL(hierarchy_kernel, dim3(grid_i), dim3(block), 0, nullptr, d_keys2, ni, d_nodes, d_pin, d_pleaf, d_first);
         LBVH_HIP(hipGetLastError());
         hipLaunchKernelGGL(refit_kernel, dim3(grid_n), dim3(block), 0, nullptr, d_sph, d_vals2, ni, d_nodes, d_pin, d_pleaf, d_arrived);
