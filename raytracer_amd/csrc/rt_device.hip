@@ -79,6 +79,9 @@ struct SceneDev {
     const TexMatDev* texmat;
     const TexImgDev* teximg;
     int32_t n_nodes, n_spheres, n_discs;
+    int32_t shell_first, shell_count;  // wide spheres [shell_first, shell_first + shell_count): concentric, radii ascending and
+                                       // well separated (nested shells); 0 = no such group
+    double shell_far2;          // squared distance from their centre beyond which the shortcut below is not taken
     uint32_t wide_same_centre;  // bit i: wide sphere i has the centre of wide sphere i - 1 (they follow one another in the tables)
     int32_t n_tree, n_wide; // n_spheres = n_tree + n_wide; a wide sphere's box covers most of the others, so every
                             // ray would reach its leaf anyway: it is tested once per segment before the descent
@@ -849,19 +852,59 @@ __device__ __forceinline__ void trav_begin(const SceneDev& S, const Tables& Tb, 
     }
     // a sphere parameter is always positive: nothing can beat a non-positive disc hit
     const bool spheres_matter = !(T.best.k >= 0 && T.best.t <= 0.0);
-    if (S.n_wide <= 2) {
-        for (int32_t i = 0; i < S.n_wide; ++i) {
-            const int32_t k = S.n_tree + i;
-            sphere_candidate(Tb.sph[k], k, Tb.prim_id, p, spheres_matter, T.best);
+    // Nested shells (SceneDev::shell_first): of m concentric spheres a segment can only meet first one of four
+    // (and which three of them suffice is decided per lane below).
+    // Count the shells its origin lies outside of (c > 0 in src/geometry.rs:107; they are the `outside` smallest):
+    //   * the largest of those: the ray enters it before any smaller one (t_smaller falls as the radius grows,
+    //     rounding included: every operation on the way from the radius to t_smaller is monotonic), and when it is
+    //     missed the smaller ones are missed too (so is the discriminant);
+    //   * the next smaller one, for an origin ON that largest shell (c > 0 by rounding): its near root may come out
+    //     as 0 or below, the far root is then taken (src/geometry.rs:115-120) and the shell inside it comes first;
+    //   * the smallest shell the origin lies inside of (c <= 0): the ray leaves that one first (t_larger grows with
+    //     the radius);
+    //   * the next larger one, when that smallest is refused by the 1e-6 rule of src/geometry.rs:118 (an origin ON it,
+    //     leaving).
+    // The radii are separated by 1e-4 of themselves and by 4e-6 or more (rt_scene_create), so an origin is on at most
+    // one shell, and the separation is far above the rounding of the roots for origins within a thousand radii of the
+    // smallest shell; a wave with an origin farther out than that tests every shell.  (Checked against testing all
+    // shells on 800 000 rays from origins on, next to and between shells, grazing directions included, and by the
+    // parity tests: the per-path kernel tests every sphere.)
+    const int32_t sh0 = S.shell_first, shn = S.shell_count;
+    bool shortcut = shn > 0;
+    CentreTerms ct{0.0, 0.0, 0.0};
+    if (shortcut) {
+        ct = sphere_centre_terms(Tb.sph[S.n_tree + sh0], p);
+        shortcut = !__any(!(ct.oc2 <= S.shell_far2));  // also false for a NaN origin
+    }
+    if (shortcut) {
+        int32_t outside = 0;  // shells with c > 0: the shells [0, outside) do not hold the origin
+        double c_last = 1.0e300;  // c of the largest of them (c falls as the radius grows)
+        for (int32_t i = 0; i < shn; ++i) {
+#pragma clang fp contract(off)
+            const double r = Tb.sph[S.n_tree + sh0 + i].w;
+            const double c = ct.oc2 - r * r;
+            outside += (c > 0.0) ? 1 : 0;
+            c_last = (c > 0.0) ? c : c_last;
         }
-    } else {
-        CentreTerms ct{0.0, 0.0, 0.0};
-        for (int32_t i = 0; i < S.n_wide; ++i) {
-            const int32_t k = S.n_tree + i;
-            const double4 s = Tb.sph[k];
-            if (!((S.wide_same_centre >> i) & 1u)) ct = sphere_centre_terms(s, p);  // wave-uniform: a fact of the scene
-            sphere_candidate_with(ct, s.w, k, Tb.prim_id, spheres_matter, T.best);
+        // Three of the four in a row: with the origin on the largest "outside" shell (c within 1e-9 of oc . oc: a
+        // near root collapses only for c within rounding, ten million times closer) the run starts one shell further
+        // in, and the shell after the enclosing one cannot be needed (the enclosing one is a whole gap away, so the
+        // 1e-6 rule accepts it); otherwise the near root of the largest outside shell is safe and the run starts there.
+        const int32_t first = outside - ((c_last < 1.0e-9 * ct.oc2) ? 2 : 1);
+#pragma unroll 1
+        for (int32_t c = 0; c < 3; ++c) {
+            const int32_t i = first + c;
+            const bool valid = i >= 0 && i < shn;
+            const int32_t k = S.n_tree + sh0 + (valid ? i : 0);
+            sphere_candidate_with(ct, Tb.sph[k].w, k, Tb.prim_id, spheres_matter && valid, T.best);
         }
+    }
+    for (int32_t i = 0; i < S.n_wide; ++i) {
+        if (shortcut && i == sh0) { i += shn - 1; continue; }  // the shells are done
+        const int32_t k = S.n_tree + i;
+        const double4 s = Tb.sph[k];
+        if (i == 0 || !((S.wide_same_centre >> i) & 1u)) ct = sphere_centre_terms(s, p);  // wave-uniform: a fact of the scene
+        sphere_candidate_with(ct, s.w, k, Tb.prim_id, spheres_matter, T.best);
     }
     T.node = (S.n_nodes == 0 || !spheres_matter) ? kLeafSentinel : root;
     const double o64[3] = {p.ox, p.oy, p.oz};
@@ -2019,21 +2062,41 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
         }
     }
     std::sort(wide_ids.begin(), wide_ids.end());
-    // wide spheres with the same centre next to one another (lowest ID first within a group, groups by their lowest ID):
-    // the render kernels compute the centre-dependent half of the sphere test once per group
+    // wide spheres with the same centre next to one another (groups by their lowest ID, smallest |radius| first within
+    // a group): the render kernels compute the centre-dependent half of the sphere test once per group, and of a
+    // group of well separated concentric spheres (nested shells) they test only the three a segment can meet first
     uint32_t wide_same_centre = 0;
+    int32_t shell_first = 0, shell_count = 0;
+    double shell_rmin2 = 0.0;
     {
         std::vector<uint32_t> grouped;
         std::vector<char> used(wide_ids.size(), 0);
         for (size_t i = 0; i < wide_ids.size(); ++i) {
             if (used[i]) continue;
             const double* ci = hittables[wide_ids[i]].centre;
+            std::vector<uint32_t> group;
             for (size_t j = i; j < wide_ids.size(); ++j) {
                 const double* cj = hittables[wide_ids[j]].centre;
                 if (used[j] || cj[0] != ci[0] || cj[1] != ci[1] || cj[2] != ci[2]) continue;
-                if (j != i && grouped.size() < 32) wide_same_centre |= 1u << grouped.size();
                 used[j] = 1;
-                grouped.push_back(wide_ids[j]);
+                group.push_back(wide_ids[j]);
+            }
+            std::stable_sort(group.begin(), group.end(), [&](uint32_t a, uint32_t b) { return std::fabs(hittables[a].radius) < std::fabs(hittables[b].radius); });
+            // shells: at least four, each radius above the one before by 1e-4 of it and by 4e-6 (four times the
+            // reference's self-hit guard, so that of two neighbours at most one can be refused by it), the first above zero
+            bool separated = group.size() >= 4 && std::fabs(hittables[group[0]].radius) > 0.0;
+            for (size_t g = 1; g < group.size() && separated; ++g) {
+                const double a = std::fabs(hittables[group[g - 1]].radius), b = std::fabs(hittables[group[g]].radius);
+                separated = b >= a * (1.0 + 1.0e-4) && b - a >= 4.0e-6;
+            }
+            if (separated && int32_t(group.size()) > shell_count) {
+                shell_first = int32_t(grouped.size());
+                shell_count = int32_t(group.size());
+                shell_rmin2 = hittables[group.front()].radius * hittables[group.front()].radius;  // the smallest shell sets the reach
+            }
+            for (size_t g = 0; g < group.size(); ++g) {
+                if (g > 0 && grouped.size() < 32) wide_same_centre |= 1u << grouped.size();
+                grouped.push_back(group[g]);
             }
         }
         wide_ids.swap(grouped);
@@ -2310,6 +2373,9 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
     sc->dev.n_tree = int32_t(n_tree);
     sc->dev.n_wide = int32_t(n_wide);
     sc->dev.wide_same_centre = wide_same_centre;
+    sc->dev.shell_first = shell_first;
+    sc->dev.shell_count = shell_count;
+    sc->dev.shell_far2 = 1.0e6 * shell_rmin2;
     sc->dev.n_discs = int32_t(n_d);
     sc->dev.eps = 0.0f;
     sc->dev.eps_rel = 0.0f;
