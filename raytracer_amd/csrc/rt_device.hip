@@ -2061,6 +2061,12 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
             tree_ids.resize(w);
         }
     }
+    // The node encoders below store a box as centre and half extent, in which the absent second child of a
+    // single-sphere tree (a far-away point box, rt_bvh.cpp) would be a box that a ray can enter.  The rules above
+    // leave either no tree or one of at least two spheres; this keeps it so whatever happens to them later.
+    if (tree_ids.size() == 1) { wide_ids.push_back(tree_ids[0]); tree_ids.clear(); }
+    if (wide_ids.size() > size_t(kSmallScene))
+        return bail(fail(RT_ERR_LIMIT, "rt_scene_create: more spheres outside the tree than the kernels test per segment"));
     std::sort(wide_ids.begin(), wide_ids.end());
     // wide spheres with the same centre next to one another (groups by their lowest ID, smallest |radius| first within
     // a group): the render kernels compute the centre-dependent half of the sphere test once per group, and of a
@@ -2225,7 +2231,11 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
             return bail(fail(RT_ERR_DEVICE, "rt_scene_create: download of the root node failed"));
         take_node(root);
     }
-    for (const Node& nd : bvh.nodes) take_node(nd);
+    for (const Node& nd : bvh.nodes) {
+        if (!(nd.lo0[0] < 3.0e38f) || !(nd.lo1[0] < 3.0e38f))  // see the single-sphere rule above
+            return bail(fail(RT_ERR_LIMIT, "rt_scene_create: a tree node with an absent child reached the node encoders"));
+        take_node(nd);
+    }
     // f16 copy of the nodes for the LDS-resident kernel: scenes that leave room for two workgroups per CU.  The
     // values are (plane - hbase) / hstep with hbase = the centre of the box above and hstep a power of two that puts
     // the half extent in [512, 1024): f16 then resolves 2^-11 of a plane's distance from the scene's centre, whatever
