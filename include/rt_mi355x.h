@@ -96,7 +96,9 @@ typedef struct rt_scene_info {
     int32_t lds_resident;  /* 1 when nodes and spheres are staged in LDS by the render kernel */
     uint32_t n_wide;       /* spheres kept out of the BVH because their box covers most of the others (tested once
                               per segment, like the discs); n_nodes counts the tree over the remaining spheres */
-    uint32_t reserved;
+    uint32_t n_shells;     /* of the n_wide spheres, those that form a group of nested shells (concentric, radii well
+                              apart): the render kernels test only the three of them a segment can meet first; 0 = no
+                              such group */
 } rt_scene_info;
 
 /* Sample range and launch options of one render call. */

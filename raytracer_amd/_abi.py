@@ -75,7 +75,7 @@ class rt_scene_info(C.Structure):
         ("device", C.c_int32),
         ("lds_resident", C.c_int32),
         ("n_wide", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("n_shells", C.c_uint32),
     ]
 
 

@@ -2424,7 +2424,7 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
     sc->info.device = device;
     sc->info.lds_resident = sc->lds_scene ? 1 : 0;
     sc->info.n_wide = uint32_t(n_wide);
-    sc->info.reserved = 0;
+    sc->info.n_shells = uint32_t(sc->dev.shell_count);
     sc->info.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     *out = sc;
     return RT_OK;

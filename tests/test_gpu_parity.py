@@ -828,6 +828,47 @@ def test_wide_spheres_outside_the_tree(rt, ob):
         assert np.array_equal(total.reshape(48, 64, 3), img), name
 
 
+def test_nested_shell_rule_edge_cases(rt):
+    """Of a group of concentric, well separated spheres the render kernels test only the three a segment can meet
+    first (chosen per lane), and every shell when an origin of the wave is far away.  The per-path entry point tests
+    every sphere of the scene, so image == ordered sum of its colours holds only if the rule never drops the nearest hit."""
+    glass, grey = rt.dielectric(1.5), rt.diffuse([.6, .5, .4])
+    lamp = rt.sphere([0, 30, 0], 8.0, rt.emitter([4, 4, 4]))
+    near = ([0, 0, 0], [0, 1.5, -6], 1.0)
+    cases = {
+        # name: (hittables, (lookat, lookfrom, inverse focal length), shells in the group)
+        "tight": ([rt.sphere([0, 0, 0], 1.0 * (1.0 + 1.2e-4) ** i, glass) for i in range(6)] + [lamp], near, 6),
+        "small_and_barely_apart_enough": ([rt.sphere([0, 0, 0], 0.03 + 5.0e-6 * i, glass) for i in range(5)] + [lamp],
+                                          ([0, 0, 0], [0, 0.05, -0.2], 1.0), 5),
+        "small_and_not_apart_enough": ([rt.sphere([0, 0, 0], 0.03 + 3.5e-6 * i, glass) for i in range(5)] + [lamp],
+                                       ([0, 0, 0], [0, 0.05, -0.2], 1.0), 0),
+        "too_close_to_be_a_group": ([rt.sphere([0, 0, 0], 1.0 + 2.0e-5 * i, glass) for i in range(5)] + [lamp], near, 0),
+        "mixed_signs": ([rt.sphere([0.3, 0.2, 0], r, glass) for r in (1.5, -1.4, 1.2, -1.1, 0.8, -0.7, 0.4)] + [lamp], near, 7),
+        "ids_interleaved": ([rt.sphere([0, 0, 0], 2.0, glass), rt.sphere([2.5, 0, 0], 0.4, grey), rt.sphere([0, 0, 0], 1.0, glass),
+                             lamp, rt.sphere([0, 0, 0], 1.5, glass), rt.sphere([0, 0, 0], 0.5, glass), rt.sphere([0, 0, 0], 1.75, glass)], near, 5),
+        # origins farther than a thousand smallest radii: the wave tests every shell (camera rays), then the
+        # scattered rays, which start on the shells, take the short way again
+        "far_camera": ([rt.sphere([0, 0, 0], 0.5 + 0.1 * i, glass) for i in range(6)] + [lamp], ([0, 0, 0], [0, 300, -1500], 0.002), 6),
+    }
+    for name, (items, (lookat, lookfrom, inv_focal), n_shells) in cases.items():
+        h = rt.hittables(items)
+        scene = rt.Scene(h)
+        assert scene.info["n_wide"] == len(items), name  # no tree: everything is tested per segment
+        assert scene.info["n_shells"] == n_shells, name
+        cam = rt.Camera.build(lookat, lookfrom, inv_focal, 0.02, 64, 48)
+        spp = 4
+        img, _ = scene.render(cam, spp, depth=50, seed=9)
+        px = np.repeat(np.arange(64 * 48, dtype=np.uint32), spp)
+        sm = np.tile(np.arange(spp, dtype=np.uint32), 64 * 48)
+        cols = scene.trace_paths(cam, px, sm, depth=50, seed=9).reshape(64 * 48, spp, 3)
+        total = np.zeros((64 * 48, 3), dtype=np.float32)
+        for k in range(spp):
+            total += cols[:, k, :]
+        assert np.array_equal(total.reshape(48, 64, 3), img), name
+        # the shells are in view: paths differ from the plain sky
+        assert np.unique(cols.reshape(-1, 3), axis=0).shape[0] > 50, name
+
+
 def test_render_multi_splits_samples_over_scene_handles(rt, scene1):
     """rt_render_multi on a one-GPU box: three handles on the same device stand in for three GPUs; the sample split,
     the concurrent renders, the peer copies and the ordered sum are the code that runs on a real node."""
