@@ -82,6 +82,7 @@ struct SceneDev {
     int32_t shell_first, shell_count;  // wide spheres [shell_first, shell_first + shell_count): concentric, radii ascending and
                                        // well separated (nested shells); 0 = no such group
     double shell_far2;          // squared distance from their centre beyond which the shortcut below is not taken
+    const double* shell_r2;     // radius * radius of those spheres (ascending), rounded as the sphere test rounds it
     uint32_t wide_same_centre;  // bit i: wide sphere i has the centre of wide sphere i - 1 (they follow one another in the tables)
     int32_t n_tree, n_wide; // n_spheres = n_tree + n_wide; a wide sphere's box covers most of the others, so every
                             // ray would reach its leaf anyway: it is tested once per segment before the descent
@@ -94,8 +95,9 @@ struct Tables {
     const float4* mat;
     const int32_t* kind;
     const int32_t* prim_id;
+    const double* shell_r2;
 };
-__device__ __forceinline__ Tables global_tables(const SceneDev& S) { return Tables{S.sph, S.mat, S.kind, S.prim_id}; }
+__device__ __forceinline__ Tables global_tables(const SceneDev& S) { return Tables{S.sph, S.mat, S.kind, S.prim_id, S.shell_r2}; }
 
 struct CamDev {
     float lookfrom[3], lookat[3], h[3], v[3];
@@ -877,15 +879,17 @@ __device__ __forceinline__ void trav_begin(const SceneDev& S, const Tables& Tb, 
         shortcut = !__any(!(ct.oc2 <= S.shell_far2));  // also false for a NaN origin
     }
     if (shortcut) {
+        // c = oc . oc - r * r is positive exactly when oc . oc > r * r (a difference of two doubles has the sign of the
+        // exact difference), so the count needs one comparison per shell against the table of squares
         int32_t outside = 0;  // shells with c > 0: the shells [0, outside) do not hold the origin
-        double c_last = 1.0e300;  // c of the largest of them (c falls as the radius grows)
+        double r2_last = -1.0e300;  // the largest of their squares
         for (int32_t i = 0; i < shn; ++i) {
-#pragma clang fp contract(off)
-            const double r = Tb.sph[S.n_tree + sh0 + i].w;
-            const double c = ct.oc2 - r * r;
-            outside += (c > 0.0) ? 1 : 0;
-            c_last = (c > 0.0) ? c : c_last;
+            const double r2 = Tb.shell_r2[i];
+            const bool out = ct.oc2 > r2;
+            outside += out ? 1 : 0;
+            r2_last = out ? r2 : r2_last;
         }
+        const double c_last = ct.oc2 - r2_last;  // c of the largest of them (huge when there is none)
         // Three of the four in a row: with the origin on the largest "outside" shell (c within 1e-9 of oc . oc: a
         // near root collapses only for c within rounding, ten million times closer) the run starts one shell further
         // in, and the shell after the enclosing one cannot be needed (the enclosing one is a whole gap away, so the
@@ -1294,7 +1298,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     uint4* lds_mat = lds_sph + (LDS16 ? 2 * S.n_spheres : 0);
     uint4* lds_kind = lds_mat + (LDS16 ? n_prims : 0);
     uint4* lds_id = lds_kind + (LDS16 ? quads : 0);
-    int32_t* stk0 = reinterpret_cast<int32_t*>(lds_id + (LDS16 ? quads : 0));
+    uint4* lds_shell = lds_id + (LDS16 ? quads : 0);
+    int32_t* stk0 = reinterpret_cast<int32_t*>(lds_shell + (LDS16 ? (S.shell_count + 1) / 2 : 0));
     int32_t* stk = stk0 + threadIdx.x;
     lds_u32* wave_state = (lds_u32*)(reinterpret_cast<uint32_t*>(stk0 + stack_depth * BLOCK) + 4 * (threadIdx.x >> 6));
     wave_state[0] = blockIdx.x % kCounters; wave_state[1] = 64; wave_state[2] = 0; wave_state[3] = 0;
@@ -1321,10 +1326,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         int32_t* kdst = reinterpret_cast<int32_t*>(lds_kind);
         int32_t* idst = reinterpret_cast<int32_t*>(lds_id);
         for (int32_t i = threadIdx.x; i < n_prims; i += BLOCK) { kdst[i] = S.kind[i]; idst[i] = S.prim_id[i]; }
+        double* rdst = reinterpret_cast<double*>(lds_shell);
+        for (int32_t i = threadIdx.x; i < S.shell_count; i += BLOCK) rdst[i] = S.shell_r2[i];
     }
     __syncthreads();
     const Tables Tb = LDS16 ? Tables{reinterpret_cast<const double4*>(lds_sph), reinterpret_cast<const float4*>(lds_mat),
-                                     reinterpret_cast<const int32_t*>(lds_kind), reinterpret_cast<const int32_t*>(lds_id)}
+                                     reinterpret_cast<const int32_t*>(lds_kind), reinterpret_cast<const int32_t*>(lds_id),
+                                     reinterpret_cast<const double*>(lds_shell)}
                             : global_tables(S);
 
     Path p;
@@ -2074,6 +2082,7 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
     uint32_t wide_same_centre = 0;
     int32_t shell_first = 0, shell_count = 0;
     double shell_rmin2 = 0.0;
+    std::vector<double> shell_r2;
     {
         std::vector<uint32_t> grouped;
         std::vector<char> used(wide_ids.size(), 0);
@@ -2099,6 +2108,8 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
                 shell_first = int32_t(grouped.size());
                 shell_count = int32_t(group.size());
                 shell_rmin2 = hittables[group.front()].radius * hittables[group.front()].radius;  // the smallest shell sets the reach
+                shell_r2.clear();
+                for (uint32_t id : group) shell_r2.push_back(hittables[id].radius * hittables[id].radius);
             }
             for (size_t g = 0; g < group.size(); ++g) {
                 if (g > 0 && grouped.size() < 32) wide_same_centre |= 1u << grouped.size();
@@ -2251,7 +2262,8 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
     {
         const size_t n_prims = n_s + n_d;
         // node halves: the first array takes kQ1Offset bytes whatever it holds (see inner_loop_lds16)
-        const size_t scene_bytes = kQ1Offset + 16 * n_nodes + 32 * n_s + 16 * n_prims + 2 * 16 * ((n_prims + 3) / 4);
+        const size_t scene_bytes = kQ1Offset + 16 * n_nodes + 32 * n_s + 16 * n_prims + 2 * 16 * ((n_prims + 3) / 4) +
+                                   16 * size_t((shell_count + 1) / 2);
         if (n_s > 0 && !resident && 16 * n_nodes <= kQ1Offset && lds16_launch_bytes(scene_bytes, sc->stack_depth) <= kLdsPerCu / 2) {
             std::vector<Node16> n16(bvh.nodes.size());
             auto rel = [&](float plane, int a) { return (double(plane) - double(sc->dev.hbase[a])) / double(sc->dev.hstep[a]); };  // exact
@@ -2386,6 +2398,7 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
     sc->dev.shell_first = shell_first;
     sc->dev.shell_count = shell_count;
     sc->dev.shell_far2 = 1.0e6 * shell_rmin2;
+    if ((rc = upload(sc, shell_r2, &sc->dev.shell_r2)) != RT_OK) return bail(rc);
     sc->dev.n_discs = int32_t(n_d);
     sc->dev.eps = 0.0f;
     sc->dev.eps_rel = 0.0f;
