@@ -838,7 +838,8 @@ __device__ __forceinline__ bool sphere_candidate(const double4 s, int32_t k, con
 // Node32 (base = the grid's low corner); GRID = false: q are the f16 values of Node16 (base = centre of the tree's
 // box, step = a power of two that brings the half extent to about 1024, inside f16's normal range whatever the
 // scene's scale).
-template <bool GRID>
+// TREE = false: the scene has no tree (a handful of spheres, all tested here): there is no descent to set up.
+template <bool GRID, bool TREE = true>
 __device__ __forceinline__ void trav_begin(const SceneDev& S, const Tables& Tb, const Path& p, Trav& T, uint32_t slot1_addr, int32_t root) {
     T.best.t = 0.0;
     T.best.k = -1;
@@ -910,7 +911,8 @@ __device__ __forceinline__ void trav_begin(const SceneDev& S, const Tables& Tb, 
         if (i == 0 || !((S.wide_same_centre >> i) & 1u)) ct = sphere_centre_terms(s, p);  // wave-uniform: a fact of the scene
         sphere_candidate_with(ct, s.w, k, Tb.prim_id, spheres_matter, T.best);
     }
-    T.node = (S.n_nodes == 0 || !spheres_matter) ? kLeafSentinel : root;
+    T.node = (!TREE || S.n_nodes == 0 || !spheres_matter) ? kLeafSentinel : root;
+    if (!TREE) return;
     const double o64[3] = {p.ox, p.oy, p.oz};
     const float df[3] = {float(p.dx), float(p.dy), float(p.dz)};
 #pragma unroll
@@ -1278,8 +1280,9 @@ __device__ __forceinline__ void leaf_step(const Tables& Tb, const Path& p, Trav&
 constexpr int kModeProduction = 0, kModeStats = 1, kModeDump = 2, kModeTiming = 3;
 
 __device__ __forceinline__ uint64_t cycle_stamp() { return __builtin_amdgcn_s_memtime(); }
-template <bool LDS16, int BLOCK, int MODE>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void render_kernel_ws(SceneDev S, CamDev C, RenderParams P,
+// TREE = false is the kernel of scenes without a tree: the shade phase alone (every sphere is tested per segment).
+template <bool LDS16, int BLOCK, int MODE, bool TREE = true>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, TREE ? 4 : 8))) void render_kernel_ws(SceneDev S, CamDev C, RenderParams P,
                                                           const Node16* __restrict__ nodes16, uint32_t stack_depth,
                                                           float* __restrict__ sum_rgb, float* __restrict__ partials,
                                                           uint32_t* __restrict__ work_counter, float* __restrict__ dump) {
@@ -1432,7 +1435,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                     normalize3(d[0], d[1], d[2]);
                     p.ox = ox; p.oy = oy; p.oz = oz;
                     unit_f64(d[0], d[1], d[2], &p.dx, &p.dy, &p.dz);
-                    trav_begin<!LDS16>(S, Tb, p, T, slot1_addr, LDS16 ? int32_t(q0_addr) : 0);
+                    trav_begin<!LDS16, TREE>(S, Tb, p, T, slot1_addr, LDS16 ? int32_t(q0_addr) : 0);
                 }
             }
         }
@@ -1449,7 +1452,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         // test "is the next node a leaf, and is the slot free" costs their inner step six instructions, which is
         // what the fuller turns give back; putting leaves off only when the inner loop pauses was slower (+5 %).
         const bool defer = STATS && (P.flags & RT_RENDER_DEFER_LEAF);
-        for (;;) {
+        for (; TREE;) {
             const uint64_t t_head = TIMING ? cycle_stamp() : 0;
             const bool descending = T.node != kLeafSentinel || (defer && pending != kLeafSentinel);
             const int n_desc = int(__popcll(__ballot(descending)));
@@ -1775,7 +1778,15 @@ struct DeviceGuard {
 };
 
 typedef void (*ws_kernel_t)(SceneDev, CamDev, RenderParams, const Node16*, uint32_t, float*, float*, uint32_t*, float*);
-ws_kernel_t ws_kernel(bool lds16, int mode) {
+ws_kernel_t ws_kernel(bool lds16, int mode, bool tree = true) {
+    if (lds16 && !tree) {
+        switch (mode) {
+        case kModeStats: return render_kernel_ws<true, kBlock, kModeStats, false>;
+        case kModeDump: return render_kernel_ws<true, kBlock, kModeDump, false>;
+        case kModeTiming: return render_kernel_ws<true, kBlock, kModeTiming, false>;
+        default: return render_kernel_ws<true, kBlock, kModeProduction, false>;
+        }
+    }
     if (lds16) {
         switch (mode) {
         case kModeStats: return render_kernel_ws<true, kBlockLds, kModeStats>;
@@ -1802,9 +1813,12 @@ int resident_blocks(rt_scene* sc, bool lockstep, bool lds16, int mode, int* out)
             RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel, kBlock, stack_bytes(sc)));
         } else if (lds16) {
             const size_t lds = lds16_launch_bytes(sc->lds16_scene_bytes, sc->stack_depth);
-            const ws_kernel_t k = ws_kernel(true, mode);
+            // a scene without a tree runs the shade-only kernel: fewer registers, so 256-thread workgroups fill the
+            // SIMDs with five waves instead of four
+            const bool tree = sc->dev.n_nodes != 0;
+            const ws_kernel_t k = ws_kernel(true, mode, tree);
             RT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsPerCu / 2)));
-            RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, kBlockLds, lds));
+            RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, tree ? kBlockLds : kBlock, lds));
         } else {
             RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ws_kernel(false, mode), kBlock, stack_bytes(sc)));
         }
@@ -2501,7 +2515,8 @@ int launch_render(rt_scene* scene, const rt_camera* cam, const rt_render_opts* o
                            d_sum_rgb, d_partials, d_work_counter);
     } else if (scene->lds_scene && !(opts->flags & RT_RENDER_KERNEL_NO_LDS_SCENE)) {
         if ((rc = resident_blocks(scene, false, true, mode, &per_cu)) != RT_OK) return rc;
-        hipLaunchKernelGGL(ws_kernel(true, mode), grid_for(per_cu, kBlockLds), dim3(kBlockLds),
+        const bool tree = scene->dev.n_nodes != 0;
+        hipLaunchKernelGGL(ws_kernel(true, mode, tree), grid_for(per_cu, tree ? kBlockLds : kBlock), dim3(tree ? kBlockLds : kBlock),
                            lds16_launch_bytes(scene->lds16_scene_bytes, scene->stack_depth), st, S, C, P, scene->d_nodes16, depth_slots,
                            d_sum_rgb, d_partials, d_work_counter, d_dump);
     } else {
@@ -2635,7 +2650,7 @@ int rt_debug_render_launch(rt_scene* scene, uint32_t* block_threads, uint32_t* w
     DeviceGuard guard;
     RT_HIP(hipSetDevice(scene->device));
     const bool lds16 = scene->lds_scene;
-    const int block = lds16 ? kBlockLds : kBlock;
+    const int block = (lds16 && scene->dev.n_nodes != 0) ? kBlockLds : kBlock;  // the shade-only kernel of a scene without a tree runs 256-thread workgroups
     int per_cu = 0;
     if (int rc = resident_blocks(scene, false, lds16, kModeProduction, &per_cu)) return rc;
     *block_threads = uint32_t(block);

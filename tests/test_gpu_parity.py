@@ -785,6 +785,12 @@ def test_render_kernel_keeps_its_occupancy(rt, scene1):
     assert big.info["lds_resident"] == 0
     _abi.check(_abi.lib.rt_debug_render_launch(big.handle, C.byref(b), C.byref(w), C.byref(s)))
     assert b.value == 256 and s.value >= 4
+    # a scene without a tree runs the shade-only kernel, which needs fewer registers: five waves per SIMD
+    grey = rt.diffuse([.5, .5, .5])
+    few = rt.Scene(rt.hittables([rt.sphere([i, 0, 0], 0.4, grey) for i in range(5)]))
+    assert few.info["n_nodes"] == 0
+    _abi.check(_abi.lib.rt_debug_render_launch(few.handle, C.byref(b), C.byref(w), C.byref(s)))
+    assert (b.value, w.value, s.value) == (256, 5, 5)
 
 
 def test_wide_spheres_outside_the_tree(rt, ob):
