@@ -869,9 +869,10 @@ __device__ __forceinline__ void trav_begin(const SceneDev& S, const Tables& Tb, 
     //     leaving).
     // The radii are separated by 1e-4 of themselves and by 4e-6 or more (rt_scene_create), so an origin is on at most
     // one shell, and the separation is far above the rounding of the roots for origins within a thousand radii of the
-    // smallest shell; a wave with an origin farther out than that tests every shell.  (Checked against testing all
-    // shells on 800 000 rays from origins on, next to and between shells, grazing directions included, and by the
-    // parity tests: the per-path kernel tests every sphere.)
+    // smallest shell; a wave with an origin farther out than that tests every shell.  (tests/test_shell_rule_model.py
+    // restates this arithmetic in numpy and checks the rule against testing all shells on rays from origins on, next
+    // to and between shells, grazing directions included; the parity tests hold this code to the per-path kernel,
+    // which tests every sphere.)
     const int32_t sh0 = S.shell_first, shn = S.shell_count;
     bool shortcut = shn > 0;
     CentreTerms ct{0.0, 0.0, 0.0};
@@ -896,9 +897,17 @@ __device__ __forceinline__ void trav_begin(const SceneDev& S, const Tables& Tb, 
         // in, and the shell after the enclosing one cannot be needed (the enclosing one is a whole gap away, so the
         // 1e-6 rule accepts it); otherwise the near root of the largest outside shell is safe and the run starts there.
         const int32_t first = outside - ((c_last < 1.0e-9 * ct.oc2) ? 2 : 1);
+        // Two of those three, by the direction: a segment that moves towards the centre (b < 0) cannot need the last
+        // of the run (it meets the enclosing shell's far side at the latest, |b| or more away), one that moves away
+        // from it (b > 0) cannot meet the first (a shell its origin is outside of by a margin lies behind it).  Near
+        // the tangent (|cos| below 5e-4, or a chord the 1e-6 rule could refuse) a grazed shell may be missed by
+        // rounding and the next one matters: a wave with such a lane tests all three.
+        const bool steep = ct.bb > 1.6e-11 && ct.bb > 1.0e-6 * ct.oc2;
+        const bool two = !__any(!steep);
+        const int32_t run_first = first + ((two && ct.b > 0.0) ? 1 : 0), run_length = two ? 2 : 3;
 #pragma unroll 1
-        for (int32_t c = 0; c < 3; ++c) {
-            const int32_t i = first + c;
+        for (int32_t c = 0; c < run_length; ++c) {
+            const int32_t i = run_first + c;
             const bool valid = i >= 0 && i < shn;
             const int32_t k = S.n_tree + sh0 + (valid ? i : 0);
             sphere_candidate_with(ct, Tb.sph[k].w, k, Tb.prim_id, spheres_matter && valid, T.best);
