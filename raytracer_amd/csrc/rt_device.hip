@@ -756,7 +756,9 @@ __global__ __launch_bounds__(kBlock) void render_kernel(SceneDev S, CamDev C, Re
 constexpr int kBlockLds = 512;      // workgroup of the LDS-resident kernel: 2 per CU = 16 waves = 4 per SIMD (128 VGPRs)
 constexpr int kTravThreshold = 12;
 constexpr int kMaxWide = 4;         // spheres kept out of the tree at most (tested linearly per segment)
+constexpr int kShellTable = 16;     // entries of the table of squared shell radii (a power of two above kSmallScene)
 constexpr int kSmallScene = 12;     // up to this many spheres no tree is built at all: every sphere is tested per segment
+static_assert(kSmallScene < kShellTable && (kShellTable & (kShellTable - 1)) == 0, "the binary search over the shell table");
 constexpr int kInnerThreshold = 8;
 constexpr int kLeaveThreshold = 48;  // lanes that may leave the inner nodes before the wave turns to the leaves (measured flat from 40 up: with the short inner step a run is best ended by kInnerThreshold alone)
 
@@ -883,12 +885,15 @@ __device__ __forceinline__ void trav_begin(const SceneDev& S, const Tables& Tb, 
     if (shortcut) {
         // c = oc . oc - r * r is positive exactly when oc . oc > r * r (a difference of two doubles has the sign of the
         // exact difference), so the count needs one comparison per shell against the table of squares
+        // The table is ascending and padded with +infinity to kShellTable entries, so the count is a binary search of
+        // four probes whatever the number of shells.
         int32_t outside = 0;  // shells with c > 0: the shells [0, outside) do not hold the origin
         double r2_last = -1.0e300;  // the largest of their squares
-        for (int32_t i = 0; i < shn; ++i) {
-            const double r2 = Tb.shell_r2[i];
-            const bool out = ct.oc2 > r2;
-            outside += out ? 1 : 0;
+#pragma unroll
+        for (int32_t step = kShellTable / 2; step >= 1; step >>= 1) {
+            const double r2 = Tb.shell_r2[outside + step - 1];
+            const bool out = ct.oc2 > r2;  // then every entry before it is below oc . oc too
+            outside += out ? step : 0;
             r2_last = out ? r2 : r2_last;
         }
         const double c_last = ct.oc2 - r2_last;  // c of the largest of them (huge when there is none)
@@ -904,14 +909,15 @@ __device__ __forceinline__ void trav_begin(const SceneDev& S, const Tables& Tb, 
         // rounding and the next one matters: a wave with such a lane tests all three.
         const bool steep = ct.bb > 1.6e-11 && ct.bb > 1.0e-6 * ct.oc2;
         const bool two = !__any(!steep);
-        const int32_t run_first = first + ((two && ct.b > 0.0) ? 1 : 0), run_length = two ? 2 : 3;
-#pragma unroll 1
-        for (int32_t c = 0; c < run_length; ++c) {
-            const int32_t i = run_first + c;
+        const int32_t run_first = first + ((two && ct.b > 0.0) ? 1 : 0);
+        auto test_shell = [&](int32_t i) {
             const bool valid = i >= 0 && i < shn;
             const int32_t k = S.n_tree + sh0 + (valid ? i : 0);
             sphere_candidate_with(ct, Tb.sph[k].w, k, Tb.prim_id, spheres_matter && valid, T.best);
-        }
+        };
+        test_shell(run_first);  // written out so that the two tests' reads and arithmetic can overlap
+        test_shell(run_first + 1);
+        if (!two) test_shell(run_first + 2);
     }
     for (int32_t i = 0; i < S.n_wide; ++i) {
         if (shortcut && i == sh0) { i += shn - 1; continue; }  // the shells are done
@@ -1311,7 +1317,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, TREE ?
     uint4* lds_kind = lds_mat + (LDS16 ? n_prims : 0);
     uint4* lds_id = lds_kind + (LDS16 ? quads : 0);
     uint4* lds_shell = lds_id + (LDS16 ? quads : 0);
-    int32_t* stk0 = reinterpret_cast<int32_t*>(lds_shell + (LDS16 ? (S.shell_count + 1) / 2 : 0));
+    int32_t* stk0 = reinterpret_cast<int32_t*>(lds_shell + ((LDS16 && S.shell_count > 0) ? kShellTable / 2 : 0));
     int32_t* stk = stk0 + threadIdx.x;
     lds_u32* wave_state = (lds_u32*)(reinterpret_cast<uint32_t*>(stk0 + stack_depth * BLOCK) + 4 * (threadIdx.x >> 6));
     wave_state[0] = blockIdx.x % kCounters; wave_state[1] = 64; wave_state[2] = 0; wave_state[3] = 0;
@@ -1339,7 +1345,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, TREE ?
         int32_t* idst = reinterpret_cast<int32_t*>(lds_id);
         for (int32_t i = threadIdx.x; i < n_prims; i += BLOCK) { kdst[i] = S.kind[i]; idst[i] = S.prim_id[i]; }
         double* rdst = reinterpret_cast<double*>(lds_shell);
-        for (int32_t i = threadIdx.x; i < S.shell_count; i += BLOCK) rdst[i] = S.shell_r2[i];
+        if (S.shell_count > 0 && threadIdx.x < kShellTable) rdst[threadIdx.x] = S.shell_r2[threadIdx.x];
     }
     __syncthreads();
     const Tables Tb = LDS16 ? Tables{reinterpret_cast<const double4*>(lds_sph), reinterpret_cast<const float4*>(lds_mat),
@@ -2133,6 +2139,7 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
                 shell_rmin2 = hittables[group.front()].radius * hittables[group.front()].radius;  // the smallest shell sets the reach
                 shell_r2.clear();
                 for (uint32_t id : group) shell_r2.push_back(hittables[id].radius * hittables[id].radius);
+                shell_r2.resize(size_t(kShellTable), HUGE_VAL);  // padding the kernels' binary search never counts
             }
             for (size_t g = 0; g < group.size(); ++g) {
                 if (g > 0 && grouped.size() < 32) wide_same_centre |= 1u << grouped.size();
@@ -2286,7 +2293,7 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
         const size_t n_prims = n_s + n_d;
         // node halves: the first array takes kQ1Offset bytes whatever it holds (see inner_loop_lds16)
         const size_t scene_bytes = kQ1Offset + 16 * n_nodes + 32 * n_s + 16 * n_prims + 2 * 16 * ((n_prims + 3) / 4) +
-                                   16 * size_t((shell_count + 1) / 2);
+                                   (shell_count > 0 ? 8 * size_t(kShellTable) : 0);
         if (n_s > 0 && !resident && 16 * n_nodes <= kQ1Offset && lds16_launch_bytes(scene_bytes, sc->stack_depth) <= kLdsPerCu / 2) {
             std::vector<Node16> n16(bvh.nodes.size());
             auto rel = [&](float plane, int a) { return (double(plane) - double(sc->dev.hbase[a])) / double(sc->dev.hstep[a]); };  // exact
