@@ -757,7 +757,8 @@ constexpr int kBlockLds = 512;      // workgroup of the LDS-resident kernel: 2 p
 constexpr int kTravThreshold = 12;
 constexpr int kMaxWide = 4;         // spheres kept out of the tree at most (tested linearly per segment)
 constexpr int kShellTable = 16;     // entries of the table of squared shell radii (a power of two above kSmallScene)
-constexpr int kSmallScene = 12;     // up to this many spheres no tree is built at all: every sphere is tested per segment
+constexpr int kSmallScene = 12;     // a scene of up to this many spheres that holds a group of nested shells gets no tree
+constexpr int kTinyScene = 5;       // up to this many spheres no scene gets a tree: every sphere is tested per segment
 static_assert(kSmallScene < kShellTable && (kShellTable & (kShellTable - 1)) == 0, "the binary search over the shell table");
 constexpr int kInnerThreshold = 8;
 constexpr int kLeaveThreshold = 48;  // lanes that may leave the inner nodes before the wave turns to the leaves (measured flat from 40 up: with the short inner step a run is best ended by kInnerThreshold alone)
@@ -2045,10 +2046,43 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
         const double x = std::max(hi[0] - lo[0], 0.0), y = std::max(hi[1] - lo[1], 0.0), z = std::max(hi[2] - lo[2], 0.0);
         return x * y + y * z + z * x;
     };
-    // A handful of spheres (nested shells, the bundled scene.json) is cheaper to test one after the other while
-    // shading, where nearly all lanes of a wave take part, than through a descent whose inner and leaf turns run half
-    // empty: such a scene has no tree, like the reference's own linear path (src/lib.rs:46-49).
-    if (sphere_ids.size() <= size_t(kSmallScene)) { wide_ids = sphere_ids; tree_ids.clear(); }
+    // Nested shells: four or more spheres with one centre, each radius above the one before by 1e-4 of it and by 4e-6
+    // (four times the reference's self-hit guard, so that of two neighbours at most one can be refused by it), the
+    // smallest above zero.  `group` comes sorted by |radius|.
+    auto well_separated = [&](const std::vector<uint32_t>& group) {
+        bool separated = group.size() >= 4 && std::fabs(hittables[group[0]].radius) > 0.0;
+        for (size_t g = 1; g < group.size() && separated; ++g) {
+            const double a = std::fabs(hittables[group[g - 1]].radius), b = std::fabs(hittables[group[g]].radius);
+            separated = b >= a * (1.0 + 1.0e-4) && b - a >= 4.0e-6;
+        }
+        return separated;
+    };
+    // the spheres of `ids` that share the centre of ids[i], from position i on, smallest |radius| first
+    auto same_centre_from = [&](const std::vector<uint32_t>& ids, size_t i, std::vector<char>* used) {
+        const double* ci = hittables[ids[i]].centre;
+        std::vector<uint32_t> group;
+        for (size_t j = i; j < ids.size(); ++j) {
+            const double* cj = hittables[ids[j]].centre;
+            if ((*used)[j] || cj[0] != ci[0] || cj[1] != ci[1] || cj[2] != ci[2]) continue;
+            (*used)[j] = 1;
+            group.push_back(ids[j]);
+        }
+        std::stable_sort(group.begin(), group.end(), [&](uint32_t a, uint32_t b) { return std::fabs(hittables[a].radius) < std::fabs(hittables[b].radius); });
+        return group;
+    };
+    // A handful of spheres (the bundled scene.json) is cheaper to test one after the other while shading, where nearly
+    // all lanes of a wave take part, than through a descent whose inner and leaf turns run half empty: such a scene
+    // has no tree, like the reference's own linear path (src/lib.rs:46-49).  So is a scene of up to a dozen spheres
+    // around a group of nested shells: a tree cannot tell concentric spheres apart, and the kernels test only two or
+    // three of the group per segment (trav_begin).  A dozen spheres that lie apart are better off with a tree (a third
+    // faster at twelve, level at five).
+    bool no_tree = sphere_ids.size() <= size_t(kTinyScene);
+    if (!no_tree && sphere_ids.size() <= size_t(kSmallScene)) {
+        std::vector<char> used(sphere_ids.size(), 0);
+        for (size_t i = 0; i < sphere_ids.size() && !no_tree; ++i)
+            if (!used[i]) no_tree = well_separated(same_centre_from(sphere_ids, i, &used));
+    }
+    if (no_tree) { wide_ids = sphere_ids; tree_ids.clear(); }
     if (tree_ids.size() >= 2) {
         // Candidates are taken largest box first, each judged against the box around all spheres still in the tree.
         // Two passes over the scene whatever the outcome: the kMaxWide + 1 largest boxes, then the box around
@@ -2117,23 +2151,8 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
         std::vector<char> used(wide_ids.size(), 0);
         for (size_t i = 0; i < wide_ids.size(); ++i) {
             if (used[i]) continue;
-            const double* ci = hittables[wide_ids[i]].centre;
-            std::vector<uint32_t> group;
-            for (size_t j = i; j < wide_ids.size(); ++j) {
-                const double* cj = hittables[wide_ids[j]].centre;
-                if (used[j] || cj[0] != ci[0] || cj[1] != ci[1] || cj[2] != ci[2]) continue;
-                used[j] = 1;
-                group.push_back(wide_ids[j]);
-            }
-            std::stable_sort(group.begin(), group.end(), [&](uint32_t a, uint32_t b) { return std::fabs(hittables[a].radius) < std::fabs(hittables[b].radius); });
-            // shells: at least four, each radius above the one before by 1e-4 of it and by 4e-6 (four times the
-            // reference's self-hit guard, so that of two neighbours at most one can be refused by it), the first above zero
-            bool separated = group.size() >= 4 && std::fabs(hittables[group[0]].radius) > 0.0;
-            for (size_t g = 1; g < group.size() && separated; ++g) {
-                const double a = std::fabs(hittables[group[g - 1]].radius), b = std::fabs(hittables[group[g]].radius);
-                separated = b >= a * (1.0 + 1.0e-4) && b - a >= 4.0e-6;
-            }
-            if (separated && int32_t(group.size()) > shell_count) {
+            const std::vector<uint32_t> group = same_centre_from(wide_ids, i, &used);
+            if (well_separated(group) && int32_t(group.size()) > shell_count) {
                 shell_first = int32_t(grouped.size());
                 shell_count = int32_t(group.size());
                 shell_rmin2 = hittables[group.front()].radius * hittables[group.front()].radius;  // the smallest shell sets the reach

@@ -736,11 +736,11 @@ def test_lbvh_tree_that_stays_on_the_device(rt, ob):
 
 def test_random_scenes_across_size_thresholds(rt, ob):
     """Random scenes of any scale and position (a tenth of the radii negative, sometimes a giant sphere underneath)
-    on both sides of every rule that depends on the sphere count: no tree (12 / 13), scene in LDS or not, tree kept
+    on both sides of every rule that depends on the sphere count: no tree (5 / 6), scene in LDS or not, tree kept
     on the device (4095 / 4096).  Both builders: nearest hits against the oracle's scan over all spheres, and the
     render kernel's image against the ordered sum of the per-path entry point's colours."""
     rng = np.random.default_rng(7)
-    for n in (1, 2, 12, 13, 300, 1500, 4095, 4096, 6000):
+    for n in (1, 2, 5, 6, 12, 13, 300, 1500, 4095, 4096, 6000):
         for giant in (False, True):
             scale = 10.0 ** rng.uniform(-2, 3)
             shift = rng.normal(0, 1, 3) * scale * 10.0 ** rng.uniform(-1, 2)
@@ -801,11 +801,15 @@ def test_wide_spheres_outside_the_tree(rt, ob):
     small = [rt.sphere(list(rng.uniform(-3, 3, 3)), 0.3, grey) for _ in range(30)]
     cases = {
         # name: (hittables, wide spheres expected)
-        # up to a dozen spheres there is no tree at all: every sphere is tested per segment
+        # up to five spheres there is no tree at all: every sphere is tested per segment
         "big_and_small": ([rt.sphere([0, 0, 0], 50.0, grey), rt.sphere([1, 0, 0], 0.5, grey)], 2),
         "concentric_pair": ([rt.sphere([0, 0, 0], 2.0, grey), rt.sphere([0, 0, 0], 1.0, grey)], 2),
-        "a_dozen": (small[:12], 12),
-        "thirteen": (small[:13], 0),
+        "five": (small[:5], 5),
+        "six": (small[:6], 0),
+        "a_dozen": (small[:12], 0),
+        # up to a dozen spheres around a group of nested shells: no tree either
+        "shells_and_a_few": ([rt.sphere([0, 0, 0], 1.0 + 0.5 * i, rt.dielectric(1.5)) for i in range(5)] + small[:7], 12),
+        "shells_and_too_many": ([rt.sphere([0, 0, 0], 1.0 + 0.5 * i, rt.dielectric(1.5)) for i in range(5)] + small[:8], 3),
         "three_shells_and_crowd": ([rt.sphere([0, 0, 0], 40.0, grey), rt.sphere([0, 0, 0], 30.0, rt.dielectric(1.5)),
                                     rt.sphere([0.5, 0, 0], 20.0, rt.dielectric(1.5))] + small, 3),
         "many_shells": ([rt.sphere([0, 0, 0], 10.0 + i, rt.dielectric(1.5)) for i in range(7)] + small, 4),  # at most four
@@ -859,8 +863,10 @@ def test_nested_shell_rule_edge_cases(rt):
     for name, (items, (lookat, lookfrom, inv_focal), n_shells) in cases.items():
         h = rt.hittables(items)
         scene = rt.Scene(h)
-        assert scene.info["n_wide"] == len(items), name  # no tree: everything is tested per segment
         assert scene.info["n_shells"] == n_shells, name
+        # around a group of shells there is no tree, everything is tested per segment; six concentric spheres that
+        # are no such group go into a tree
+        assert scene.info["n_wide"] == (len(items) if n_shells else 0) and (scene.info["n_nodes"] == 0) == (n_shells > 0), name
         cam = rt.Camera.build(lookat, lookfrom, inv_focal, 0.02, 64, 48)
         spp = 4
         img, _ = scene.render(cam, spp, depth=50, seed=9)

@@ -438,8 +438,8 @@ int main() {
     CHECK(hipMalloc(&d_tree_c, tree_c.size() * 4));
     CHECK(hipMemcpy(d_tree_c, tree_c.data(), tree_c.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMalloc(&d_out, 16 + 1024 * 8));
-    const char* names[11] = {"loop as run (round 2)", "no exit test", "no push/pop", "vector select", "scalar logic spread", "node halves side by side",
-                            "clamp for v_max/v_min", "dot2 + clamp", "4-child node, dot2", "loop as run (round 3a)", "restructured"};
+    const char* names[11] = {"earlier loop (56 instr.)", "no exit test", "no push/pop", "vector select", "scalar logic spread", "node halves side by side",
+                            "clamp for v_max/v_min", "dot2 + clamp", "4-child node, dot2", "earlier loop, LDS links", "loop as run (49 instr.)"};
     const int boxes[11] = {2, 2, 2, 2, 2, 2, 2, 2, 4, 2, 2};
     std::printf("%-24s %14s %14s %14s %16s   (SIMD cycles per step of one wave, 64 lanes on)\n", "variant", "1 wave/SIMD", "2 waves/SIMD",
                 "4 waves/SIMD", "per box, 4 w/SIMD");
