@@ -1150,11 +1150,116 @@ __device__ __forceinline__ void inner_loop_lds16(Trav& T, int32_t thr) {
           "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
 }
 
+#define RT_HBM_LOOP(B) \
+  /* which lanes stand on an inner node, and whether to run at all */ \
+        "v_cmp_lt_i32_e32 vcc, -1, %[node]\n\t" \
+        "s_mov_b64 s[88:89], exec\n\t" \
+        "s_bcnt1_i32_b64 %[cnt], vcc\n\t" \
+        "s_cmp_ge_i32 %[cnt], %[thr]\n\t" \
+        "s_cbranch_scc1 4f\n\t" \
+        "s_cmp_eq_u32 %[cnt], 0\n\t" \
+        "s_cbranch_scc1 9f\n\t" \
+        "v_cmp_lt_u32_e64 s[90:91], %[sentinel], %[node]\n\t"  /* as unsigned: above the sentinel = a leaf */ \
+        "s_cmp_lg_u64 s[90:91], 0\n\t" \
+        "s_cbranch_scc1 9f\n\t" \
+        "4:\n\t" \
+        "s_mov_b64 exec, vcc\n\t" \
+        "v_lshlrev_b32_e32 v[" B "+0], 5, %[node]\n\t" \
+        "global_load_dwordx4 v[" B "+8:" B "+11], v[" B "+0], %[base]\n\t" \
+        "global_load_dwordx4 v[" B "+12:" B "+15], v[" B "+0], %[base] offset:16\n\t" \
+        "1:\n\t" \
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" \
+  /* x: register 8 of the block = centres (child 0 | child 1), register 9 = half extents */ \
+        "v_cvt_f32_u32_sdwa v[" B "+0], v[" B "+8] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t" \
+        "v_cvt_f32_u32_sdwa v[" B "+1], v[" B "+8] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t" \
+        "v_cvt_f32_u32_sdwa v[" B "+2], v[" B "+9] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t" \
+        "v_cvt_f32_u32_sdwa v[" B "+3], v[" B "+9] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t" \
+        "v_pk_fma_f32 v[" B "+0:" B "+1], v[" B "+0:" B "+1], %[px], %[qx] op_sel_hi:[1,0,0]\n\t"  /* centres * inv + A, both children */ \
+        "v_pk_fma_f32 v[" B "+2:" B "+3], v[" B "+2:" B "+3], %[px], %[qx] op_sel:[0,1,1] op_sel_hi:[1,1,1]\n\t"  /* half extents * |inv| + E */ \
+        "v_pk_add_f32 v[" B "+4:" B "+5], v[" B "+0:" B "+1], v[" B "+2:" B "+3] neg_lo:[0,1] neg_hi:[0,1]\n\t"  /* near parameters */ \
+        "v_pk_add_f32 v[" B "+0:" B "+1], v[" B "+0:" B "+1], v[" B "+2:" B "+3]\n\t"  /* far parameters */ \
+  /* y: registers 10 and 11 */ \
+        "v_cvt_f32_u32_sdwa v[" B "+2], v[" B "+10] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t" \
+        "v_cvt_f32_u32_sdwa v[" B "+3], v[" B "+10] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t" \
+        "v_cvt_f32_u32_sdwa v[" B "+8], v[" B "+11] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t" \
+        "v_cvt_f32_u32_sdwa v[" B "+9], v[" B "+11] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t" \
+        "v_pk_fma_f32 v[" B "+2:" B "+3], v[" B "+2:" B "+3], %[py], %[qy] op_sel_hi:[1,0,0]\n\t"  /* centres * inv + A, both children */ \
+        "v_pk_fma_f32 v[" B "+8:" B "+9], v[" B "+8:" B "+9], %[py], %[qy] op_sel:[0,1,1] op_sel_hi:[1,1,1]\n\t"  /* half extents * |inv| + E */ \
+        "v_pk_add_f32 v[" B "+6:" B "+7], v[" B "+2:" B "+3], v[" B "+8:" B "+9] neg_lo:[0,1] neg_hi:[0,1]\n\t"  /* near parameters */ \
+        "v_pk_add_f32 v[" B "+2:" B "+3], v[" B "+2:" B "+3], v[" B "+8:" B "+9]\n\t"  /* far parameters */ \
+  /* z: registers 12 and 13 */ \
+        "v_cvt_f32_u32_sdwa v[" B "+8], v[" B "+12] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t" \
+        "v_cvt_f32_u32_sdwa v[" B "+9], v[" B "+12] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t" \
+        "v_cvt_f32_u32_sdwa v[" B "+10], v[" B "+13] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t" \
+        "v_cvt_f32_u32_sdwa v[" B "+11], v[" B "+13] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t" \
+        "v_pk_fma_f32 v[" B "+8:" B "+9], v[" B "+8:" B "+9], %[pz], %[qz] op_sel_hi:[1,0,0]\n\t"  /* centres * inv + A, both children */ \
+        "v_pk_fma_f32 v[" B "+10:" B "+11], v[" B "+10:" B "+11], %[pz], %[qz] op_sel:[0,1,1] op_sel_hi:[1,1,1]\n\t"  /* half extents * |inv| + E */ \
+        "v_pk_add_f32 v[" B "+12:" B "+13], v[" B "+8:" B "+9], v[" B "+10:" B "+11]\n\t"  /* far parameters */ \
+        "v_pk_add_f32 v[" B "+10:" B "+11], v[" B "+8:" B "+9], v[" B "+10:" B "+11] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"  /* near parameters, clamped to [0, 1]: max(., 0) for free */ \
+  /* near x / y / z = registers 4,5 / 6,7 / 10,11; far = 0,1 / 2,3 / 12,13 (child 0, child 1) */ \
+        "v_min_f32_e32 v[" B "+12], v[" B "+12], %[tmax]\n\t" \
+        "v_min_f32_e32 v[" B "+13], v[" B "+13], %[tmax]\n\t" \
+        "v_max3_f32 v[" B "+4], v[" B "+4], v[" B "+6], v[" B "+10]\n\t"  /* entry parameter of child 0 */ \
+        "v_min3_f32 v[" B "+0], v[" B "+0], v[" B "+2], v[" B "+12]\n\t"  /* exit parameter of child 0 */ \
+        "v_max3_f32 v[" B "+5], v[" B "+5], v[" B "+7], v[" B "+11]\n\t"  /* entry parameter of child 1 */ \
+        "v_min3_f32 v[" B "+1], v[" B "+1], v[" B "+3], v[" B "+13]\n\t"  /* exit parameter of child 1 */ \
+  /* registers 14, 15 = child links c0, c1 */ \
+        "v_cmp_le_f32_e64 s[90:91], v[" B "+4], v[" B "+0]\n\t"  /* h0 */ \
+        "v_cmp_le_f32_e64 s[92:93], v[" B "+5], v[" B "+1]\n\t"  /* h1 */ \
+        "v_cmp_lt_f32_e64 s[94:95], v[" B "+5], v[" B "+4]\n\t"  /* child 1 is entered first */ \
+        "s_and_b64 s[96:97], s[90:91], s[92:93]\n\t"  /* both */ \
+        "s_or_b64 s[98:99], s[90:91], s[92:93]\n\t"  /* any */ \
+        "s_and_b64 s[94:95], s[94:95], s[92:93]\n\t" \
+        "s_andn2_b64 s[94:95], s[90:91], s[94:95]\n\t"  /* go to c0: h0 and not (h1 and child 1 first) */ \
+        "s_andn2_b64 s[98:99], exec, s[98:99]\n\t"  /* none */ \
+        "v_cndmask_b32_e64 %[node], v[" B "+15], v[" B "+14], s[94:95]\n\t" \
+        "v_cndmask_b32_e64 v[" B "+6], v[" B "+14], v[" B "+15], s[94:95]\n\t"  /* the other child, pushed where both are hit */ \
+        "v_cndmask_b32_e64 %[node], %[node], %[top], s[98:99]\n\t"  /* no child hit: go on with the stack top */ \
+  /* every lane's next node is known: decide whether the loop goes on, and if so start the next fetch before */ \
+  /* the stack is brought up to date */ \
+        "v_cmp_lt_i32_e32 vcc, -1, %[node]\n\t" \
+        "s_bcnt1_i32_b64 %[cnt], vcc\n\t" \
+        "s_cmp_ge_i32 %[cnt], %[thr]\n\t" \
+        "s_cbranch_scc0 5f\n\t" \
+        "6:\n\t" \
+        "s_mov_b64 exec, vcc\n\t" \
+        "v_lshlrev_b32_e32 v[" B "+0], 5, %[node]\n\t" \
+        "global_load_dwordx4 v[" B "+8:" B "+11], v[" B "+0], %[base]\n\t" \
+        "global_load_dwordx4 v[" B "+12:" B "+15], v[" B "+0], %[base] offset:16\n\t" \
+        "s_mov_b64 exec, s[96:97]\n\t"  /* push */ \
+        "ds_write_b32 %[sp], %[top]\n\t" \
+        "v_add_u32_e32 %[sp], %[stride], %[sp]\n\t" \
+        "v_mov_b32_e32 %[top], v[" B "+6]\n\t" \
+        "s_mov_b64 exec, s[98:99]\n\t"  /* pop */ \
+        "v_subrev_u32_e32 %[sp], %[stride], %[sp]\n\t" \
+        "ds_read_b32 %[top], %[sp]\n\t" \
+        "s_mov_b64 exec, vcc\n\t" \
+        "s_branch 1b\n\t" \
+        "5:\n\t"  /* fewer than `thr` lanes go on: leave when none does, or when some lane of the wave waits at a leaf */ \
+        "s_cmp_eq_u32 %[cnt], 0\n\t" \
+        "s_cbranch_scc1 7f\n\t" \
+        "s_mov_b64 exec, s[88:89]\n\t" \
+        "v_cmp_lt_u32_e64 s[90:91], %[sentinel], %[node]\n\t" \
+        "s_cmp_lg_u64 s[90:91], 0\n\t" \
+        "s_cbranch_scc0 6b\n\t" \
+        "7:\n\t" \
+        "s_mov_b64 exec, s[96:97]\n\t"  /* push */ \
+        "ds_write_b32 %[sp], %[top]\n\t" \
+        "v_add_u32_e32 %[sp], %[stride], %[sp]\n\t" \
+        "v_mov_b32_e32 %[top], v[" B "+6]\n\t" \
+        "s_mov_b64 exec, s[98:99]\n\t"  /* pop */ \
+        "v_subrev_u32_e32 %[sp], %[stride], %[sp]\n\t" \
+        "ds_read_b32 %[top], %[sp]\n\t" \
+        "9:\n\t" \
+        "s_mov_b64 exec, s[88:89]\n\t" \
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
 // The same loop for the tree in HBM (Node32: boxes as 16-bit grid indices, the grid folded into T.inv / T.A / T.B
 // by trav_begin<true>): two 16-byte global loads per node, 12 conversions + 6 packed FMAs (both children of an axis
 // at once; the pairs {inv, |inv|} and {A, E} are broadcast by op_sel) instead of the 12 mixed FMAs.
 // The node's byte offset (index * 32) is formed in 32 bits: rt_scene_create admits at most 2^26 spheres in a tree.
-template <int BLOCK>
+// LOW: the block's sixteen vector registers are v80-v95 instead of v112-v127, for the build of the kernel that runs five
+// waves per SIMD (96 registers).
+template <int BLOCK, bool LOW>
 __device__ __forceinline__ void inner_loop_hbm(Trav& T, const Node32* nodes32, int32_t thr) {
     static_assert(BLOCK == 512 || BLOCK == 256, "stack column stride");
     // scalar registers for the "s" operands, as in inner_loop_lds16
@@ -1163,117 +1268,26 @@ __device__ __forceinline__ void inner_loop_hbm(Trav& T, const Node32* nodes32, i
     const uint64_t base = uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int32_t(uint32_t(base_bits))))) |
                           (uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int32_t(uint32_t(base_bits >> 32))))) << 32);
     int32_t lanes_on_inner;
-    asm volatile(
-        // which lanes stand on an inner node, and whether to run at all
-        "v_cmp_lt_i32_e32 vcc, -1, %[node]\n\t"
-        "s_mov_b64 s[88:89], exec\n\t"
-        "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
-        "s_cmp_ge_i32 %[cnt], %[thr]\n\t"
-        "s_cbranch_scc1 4f\n\t"
-        "s_cmp_eq_u32 %[cnt], 0\n\t"
-        "s_cbranch_scc1 9f\n\t"
-        "v_cmp_lt_u32_e64 s[90:91], %[sentinel], %[node]\n\t"  // as unsigned: above the sentinel = a leaf
-        "s_cmp_lg_u64 s[90:91], 0\n\t"
-        "s_cbranch_scc1 9f\n\t"
-        "4:\n\t"
-        "s_mov_b64 exec, vcc\n\t"
-        "v_lshlrev_b32_e32 v112, 5, %[node]\n\t"
-        "global_load_dwordx4 v[120:123], v112, %[base]\n\t"
-        "global_load_dwordx4 v[124:127], v112, %[base] offset:16\n\t"
-        "1:\n\t"
-        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
-        // x: v120 = centres (child 0 | child 1), v121 = half extents
-        "v_cvt_f32_u32_sdwa v112, v120 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
-        "v_cvt_f32_u32_sdwa v113, v120 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-        "v_cvt_f32_u32_sdwa v114, v121 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
-        "v_cvt_f32_u32_sdwa v115, v121 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-        "v_pk_fma_f32 v[112:113], v[112:113], %[px], %[qx] op_sel_hi:[1,0,0]\n\t"   // centres * inv + A, both children
-        "v_pk_fma_f32 v[114:115], v[114:115], %[px], %[qx] op_sel:[0,1,1] op_sel_hi:[1,1,1]\n\t"   // half extents * |inv| + E
-        "v_pk_add_f32 v[116:117], v[112:113], v[114:115] neg_lo:[0,1] neg_hi:[0,1]\n\t"   // near parameters
-        "v_pk_add_f32 v[112:113], v[112:113], v[114:115]\n\t"   // far parameters
-        // y: v122 = centres (child 0 | child 1), v123 = half extents
-        "v_cvt_f32_u32_sdwa v114, v122 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
-        "v_cvt_f32_u32_sdwa v115, v122 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-        "v_cvt_f32_u32_sdwa v120, v123 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
-        "v_cvt_f32_u32_sdwa v121, v123 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-        "v_pk_fma_f32 v[114:115], v[114:115], %[py], %[qy] op_sel_hi:[1,0,0]\n\t"   // centres * inv + A, both children
-        "v_pk_fma_f32 v[120:121], v[120:121], %[py], %[qy] op_sel:[0,1,1] op_sel_hi:[1,1,1]\n\t"   // half extents * |inv| + E
-        "v_pk_add_f32 v[118:119], v[114:115], v[120:121] neg_lo:[0,1] neg_hi:[0,1]\n\t"   // near parameters
-        "v_pk_add_f32 v[114:115], v[114:115], v[120:121]\n\t"   // far parameters
-        // z: v124 = centres (child 0 | child 1), v125 = half extents
-        "v_cvt_f32_u32_sdwa v120, v124 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
-        "v_cvt_f32_u32_sdwa v121, v124 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-        "v_cvt_f32_u32_sdwa v122, v125 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"
-        "v_cvt_f32_u32_sdwa v123, v125 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-        "v_pk_fma_f32 v[120:121], v[120:121], %[pz], %[qz] op_sel_hi:[1,0,0]\n\t"   // centres * inv + A, both children
-        "v_pk_fma_f32 v[122:123], v[122:123], %[pz], %[qz] op_sel:[0,1,1] op_sel_hi:[1,1,1]\n\t"   // half extents * |inv| + E
-        "v_pk_add_f32 v[124:125], v[120:121], v[122:123]\n\t"   // far parameters
-        "v_pk_add_f32 v[122:123], v[120:121], v[122:123] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"   // near parameters, clamped to [0, 1]: max(., 0) for free
-        // near x / y / z = v116,117 / v118,119 / v122,123; far = v112,113 / v114,115 / v124,125 (child 0, child 1)
-        "v_min_f32_e32 v124, v124, %[tmax]\n\t"
-        "v_min_f32_e32 v125, v125, %[tmax]\n\t"
-        "v_max3_f32 v116, v116, v118, v122\n\t"   // entry parameter of child 0
-        "v_min3_f32 v112, v112, v114, v124\n\t"   // exit parameter of child 0
-        "v_max3_f32 v117, v117, v119, v123\n\t"   // entry parameter of child 1
-        "v_min3_f32 v113, v113, v115, v125\n\t"   // exit parameter of child 1
-        // v126, v127 = child links c0, c1
-        "v_cmp_le_f32_e64 s[90:91], v116, v112\n\t"   // h0
-        "v_cmp_le_f32_e64 s[92:93], v117, v113\n\t"   // h1
-        "v_cmp_lt_f32_e64 s[94:95], v117, v116\n\t"   // child 1 is entered first
-        "s_and_b64 s[96:97], s[90:91], s[92:93]\n\t"  // both
-        "s_or_b64 s[98:99], s[90:91], s[92:93]\n\t"   // any
-        "s_and_b64 s[94:95], s[94:95], s[92:93]\n\t"
-        "s_andn2_b64 s[94:95], s[90:91], s[94:95]\n\t"  // go to c0: h0 and not (h1 and child 1 first)
-        "s_andn2_b64 s[98:99], exec, s[98:99]\n\t"      // none
-        "v_cndmask_b32_e64 %[node], v127, v126, s[94:95]\n\t"
-        "v_cndmask_b32_e64 v118, v126, v127, s[94:95]\n\t"  // the other child, pushed where both are hit
-        "v_cndmask_b32_e64 %[node], %[node], %[top], s[98:99]\n\t"  // no child hit: go on with the stack top
-        // every lane's next node is known: decide whether the loop goes on, and if so start the next fetch before
-        // the stack is brought up to date
-        "v_cmp_lt_i32_e32 vcc, -1, %[node]\n\t"
-        "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
-        "s_cmp_ge_i32 %[cnt], %[thr]\n\t"
-        "s_cbranch_scc0 5f\n\t"
-        "6:\n\t"
-        "s_mov_b64 exec, vcc\n\t"
-        "v_lshlrev_b32_e32 v112, 5, %[node]\n\t"
-        "global_load_dwordx4 v[120:123], v112, %[base]\n\t"
-        "global_load_dwordx4 v[124:127], v112, %[base] offset:16\n\t"
-        "s_mov_b64 exec, s[96:97]\n\t"               // push
-        "ds_write_b32 %[sp], %[top]\n\t"
-        "v_add_u32_e32 %[sp], %[stride], %[sp]\n\t"
-        "v_mov_b32_e32 %[top], v118\n\t"
-        "s_mov_b64 exec, s[98:99]\n\t"               // pop
-        "v_subrev_u32_e32 %[sp], %[stride], %[sp]\n\t"
-        "ds_read_b32 %[top], %[sp]\n\t"
-        "s_mov_b64 exec, vcc\n\t"
-        "s_branch 1b\n\t"
-        "5:\n\t"  // fewer than `thr` lanes go on: leave when none does, or when some lane of the wave waits at a leaf
-        "s_cmp_eq_u32 %[cnt], 0\n\t"
-        "s_cbranch_scc1 7f\n\t"
-        "s_mov_b64 exec, s[88:89]\n\t"
-        "v_cmp_lt_u32_e64 s[90:91], %[sentinel], %[node]\n\t"
-        "s_cmp_lg_u64 s[90:91], 0\n\t"
-        "s_cbranch_scc0 6b\n\t"
-        "7:\n\t"
-        "s_mov_b64 exec, s[96:97]\n\t"               // push
-        "ds_write_b32 %[sp], %[top]\n\t"
-        "v_add_u32_e32 %[sp], %[stride], %[sp]\n\t"
-        "v_mov_b32_e32 %[top], v118\n\t"
-        "s_mov_b64 exec, s[98:99]\n\t"               // pop
-        "v_subrev_u32_e32 %[sp], %[stride], %[sp]\n\t"
-        "ds_read_b32 %[top], %[sp]\n\t"
-        "9:\n\t"
-        "s_mov_b64 exec, s[88:89]\n\t"
-        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+    if constexpr (LOW) {
+        asm volatile(RT_HBM_LOOP("80")
         : [node] "+v"(T.node), [sp] "+v"(T.sp), [top] "+v"(T.top), [cnt] "=&s"(lanes_on_inner)
         : [px] "v"(T.inv_abs[0]), [py] "v"(T.inv_abs[1]), [pz] "v"(T.inv_abs[2]), [qx] "v"(T.A_E[0]), [qy] "v"(T.A_E[1]),
           [qz] "v"(T.A_E[2]), [tmax] "v"(T.tmax),
           [base] "s"(base), [thr] "s"(thr), [sentinel] "s"(kLeafSentinel),
           [stride] "s"(uint32_t(BLOCK * sizeof(int32_t)))
-        : "memory", "vcc", "scc", "v112", "v113", "v114", "v115", "v116", "v117",
-          "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "s88", "s89", "s90", "s91",
+        : "memory", "vcc", "scc", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "s88", "s89", "s90", "s91",
           "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
+    } else {
+        asm volatile(RT_HBM_LOOP("112")
+        : [node] "+v"(T.node), [sp] "+v"(T.sp), [top] "+v"(T.top), [cnt] "=&s"(lanes_on_inner)
+        : [px] "v"(T.inv_abs[0]), [py] "v"(T.inv_abs[1]), [pz] "v"(T.inv_abs[2]), [qx] "v"(T.A_E[0]), [qy] "v"(T.A_E[1]),
+          [qz] "v"(T.A_E[2]), [tmax] "v"(T.tmax),
+          [base] "s"(base), [thr] "s"(thr), [sentinel] "s"(kLeafSentinel),
+          [stride] "s"(uint32_t(BLOCK * sizeof(int32_t)))
+        : "memory", "vcc", "scc", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "s88", "s89", "s90", "s91",
+          "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
+    }
+
 }
 
 template <bool LDS16, int BLOCK>
@@ -1297,8 +1311,10 @@ constexpr int kModeProduction = 0, kModeStats = 1, kModeDump = 2, kModeTiming = 
 
 __device__ __forceinline__ uint64_t cycle_stamp() { return __builtin_amdgcn_s_memtime(); }
 // TREE = false is the kernel of scenes without a tree: the shade phase alone (every sphere is tested per segment).
-template <bool LDS16, int BLOCK, int MODE, bool TREE = true>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, TREE ? 4 : 8))) void render_kernel_ws(SceneDev S, CamDev C, RenderParams P,
+// FIVE = true (tree in HBM only): built for 96 vector registers, five waves per SIMD; chosen when five workgroups' stacks
+// fit the CU's LDS (resident_blocks).
+template <bool LDS16, int BLOCK, int MODE, bool TREE = true, bool FIVE = false>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FIVE ? 5 : 4, TREE ? (FIVE ? 5 : 4) : 8))) void render_kernel_ws(SceneDev S, CamDev C, RenderParams P,
                                                           const Node16* __restrict__ nodes16, uint32_t stack_depth,
                                                           float* __restrict__ sum_rgb, float* __restrict__ partials,
                                                           uint32_t* __restrict__ work_counter, float* __restrict__ dump) {
@@ -1484,7 +1500,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, TREE ?
             if (LDS16 && !STATS) {
                 inner_loop_lds16<BLOCK>(T, run_threshold);
             } else if (!STATS) {
-                inner_loop_hbm<BLOCK>(T, S.nodes32, run_threshold);
+                inner_loop_hbm<BLOCK, FIVE>(T, S.nodes32, run_threshold);
             } else {
                 for (;;) {
                     const int n_inner = int(__popcll(__ballot(T.node >= 0)));
@@ -1671,6 +1687,7 @@ struct rt_scene {
     // workgroups per CU of each render kernel variant for this scene's LDS footprint, 0 = not asked yet
     // ([0] lock-step kernel, [1 + mode] wave-scheduled kernel with the tree in HBM, [5 + mode] with the scene in LDS)
     int per_cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int five_waves = -1;  // tree in HBM: 1 = the kernel built for five waves per SIMD is used, 0 = the four-wave one, -1 = not decided yet
 };
 
 namespace {
@@ -1794,7 +1811,15 @@ struct DeviceGuard {
 };
 
 typedef void (*ws_kernel_t)(SceneDev, CamDev, RenderParams, const Node16*, uint32_t, float*, float*, uint32_t*, float*);
-ws_kernel_t ws_kernel(bool lds16, int mode, bool tree = true) {
+ws_kernel_t ws_kernel(bool lds16, int mode, bool tree = true, bool five = false) {
+    if (!lds16 && five) {
+        switch (mode) {
+        case kModeStats: return render_kernel_ws<false, kBlock, kModeStats, true, true>;
+        case kModeDump: return render_kernel_ws<false, kBlock, kModeDump, true, true>;
+        case kModeTiming: return render_kernel_ws<false, kBlock, kModeTiming, true, true>;
+        default: return render_kernel_ws<false, kBlock, kModeProduction, true, true>;
+        }
+    }
     if (lds16 && !tree) {
         switch (mode) {
         case kModeStats: return render_kernel_ws<true, kBlock, kModeStats, false>;
@@ -1821,6 +1846,20 @@ ws_kernel_t ws_kernel(bool lds16, int mode, bool tree = true) {
 
 // Workgroups per CU of one kernel variant for this scene (asked once per scene and variant, then remembered;
 // the production variant is asked when the scene is created, so a render call makes no query).
+// Tree in HBM: whether the scene runs the kernel built for five waves per SIMD (96 registers, a few of them spilled;
+// 1 M spheres: 24.9 -> 24.0 ms).  It does when five workgroups' traversal stacks fit the CU's LDS; a deeper tree keeps
+// the four-wave kernel, which has all its registers.
+int use_five_waves(rt_scene* sc, bool* five) {
+    if (sc->five_waves < 0) {
+        int per_cu = 0;
+        RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ws_kernel(false, kModeProduction, true, true), kBlock, stack_bytes(sc)));
+        sc->five_waves = per_cu >= 5 ? 1 : 0;
+        if (const char* e = std::getenv("RT_HBM_FIVE_WAVES")) sc->five_waves = std::atoi(e) ? 1 : 0;  // tuning aid
+    }
+    *five = sc->five_waves == 1;
+    return RT_OK;
+}
+
 int resident_blocks(rt_scene* sc, bool lockstep, bool lds16, int mode, int* out) {
     int& slot = sc->per_cu[lockstep ? 0 : 1 + (lds16 ? 4 : 0) + mode];
     if (slot == 0) {
@@ -1836,7 +1875,9 @@ int resident_blocks(rt_scene* sc, bool lockstep, bool lds16, int mode, int* out)
             RT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsPerCu / 2)));
             RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, tree ? kBlockLds : kBlock, lds));
         } else {
-            RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ws_kernel(false, mode), kBlock, stack_bytes(sc)));
+            bool five = false;
+            if (int rc = use_five_waves(sc, &five)) return rc;
+            RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ws_kernel(false, mode, true, five), kBlock, stack_bytes(sc)));
         }
         slot = per_cu < 1 ? 1 : per_cu;
     }
@@ -2556,7 +2597,9 @@ int launch_render(rt_scene* scene, const rt_camera* cam, const rt_render_opts* o
                            d_sum_rgb, d_partials, d_work_counter, d_dump);
     } else {
         if ((rc = resident_blocks(scene, false, false, mode, &per_cu)) != RT_OK) return rc;
-        hipLaunchKernelGGL(ws_kernel(false, mode), grid_for(per_cu, kBlock), dim3(kBlock), stack_bytes(scene), st, S, C, P,
+        bool five = false;
+        if ((rc = use_five_waves(scene, &five)) != RT_OK) return rc;
+        hipLaunchKernelGGL(ws_kernel(false, mode, true, five), grid_for(per_cu, kBlock), dim3(kBlock), stack_bytes(scene), st, S, C, P,
                            static_cast<const Node16*>(nullptr), depth_slots, d_sum_rgb, d_partials, d_work_counter, d_dump);
     }
     RT_HIP(hipGetLastError());

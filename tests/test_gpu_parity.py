@@ -784,13 +784,13 @@ def test_render_kernel_keeps_its_occupancy(rt, scene1):
     big = rt.Scene(rt.gen_scene_grid(1, 60))  # 3601 spheres: too large for LDS
     assert big.info["lds_resident"] == 0
     _abi.check(_abi.lib.rt_debug_render_launch(big.handle, C.byref(b), C.byref(w), C.byref(s)))
-    assert b.value == 256 and s.value >= 4
+    assert b.value == 256 and s.value == 5  # shallow tree: five workgroups' stacks fit LDS, the five-wave build runs
     # a scene without a tree runs the shade-only kernel, which needs fewer registers: five waves per SIMD
     grey = rt.diffuse([.5, .5, .5])
     few = rt.Scene(rt.hittables([rt.sphere([i, 0, 0], 0.4, grey) for i in range(5)]))
     assert few.info["n_nodes"] == 0
     _abi.check(_abi.lib.rt_debug_render_launch(few.handle, C.byref(b), C.byref(w), C.byref(s)))
-    assert (b.value, w.value, s.value) == (256, 5, 5)
+    assert b.value == 256 and w.value == s.value and s.value >= 5
 
 
 def test_wide_spheres_outside_the_tree(rt, ob):
