@@ -24,7 +24,7 @@ tot = collections.OrderedDict()
 for f in sorted(glob.glob(out + '/*/*/*counter_collection.csv')):
     for row in csv.DictReader(open(f)):
         if 'render_kernel' not in row['Kernel_Name']: continue
-        if re.search(r'render_kernel_ws<\w+, \d+, [123](, \w+)?>', row['Kernel_Name']): continue  # diagnostic builds (bench.py's segment count launch)
+        if re.search(r'render_kernel_ws<\w+, \d+, [123](, \w+)*>', row['Kernel_Name']): continue  # diagnostic builds (bench.py's segment count launch)
         tot[row['Counter_Name']] = tot.get(row['Counter_Name'], 0.0) + float(row['Counter_Value'])
 with open(out + '/summary.txt', 'w') as fh:
     for k, v in tot.items():
