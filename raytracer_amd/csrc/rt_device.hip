@@ -764,6 +764,7 @@ constexpr int kInnerThreshold = 8;
 constexpr int kLeaveThreshold = 48;  // lanes that may leave the inner nodes before the wave turns to the leaves (measured flat from 40 up: with the short inner step a run is best ended by kInnerThreshold alone)
 
 constexpr uint32_t kQ1Offset = 12288;  // LDS bytes from a node's first half to its second (inner_loop_lds16): room for 768 nodes
+constexpr uint32_t kQ1OffsetFive = 8192;  // the same in the five-wave build of the kernel, which keeps less in LDS: 512 nodes
 struct Node16 {       // 32 bytes: two 16-byte LDS reads
     uint16_t h[12];   // IEEE half bits; per axis x, y, z: centre of child 0, of child 1, half extent of child 0, of child 1
     int32_t child0, child1;
@@ -1050,104 +1051,116 @@ __device__ __forceinline__ void inner_step(const SceneDev& S, const uint4* lds_q
 // inline-asm operands cannot name the dwords of a tuple).  EXEC is narrowed inside and restored before leaving.
 #define RT_STR2(x) #x
 #define RT_STR(x) RT_STR2(x)
-#define RT_FETCH16 "ds_read_b128 v[120:123], %[node]\n\tds_read_b128 v[124:127], %[node] offset:" RT_STR(12288) "\n\t"
-static_assert(kQ1Offset == 12288, "RT_FETCH16 spells the offset out");
-template <int BLOCK>
+// (The loop is a macro of the block's register base and of the distance to a node's second half, both as string
+// literals, because the kernel is built twice: see render_kernel_ws.  rN in the remarks = register base + N.)
+#define RT_LDS_LOOP(B, Q1) \
+  /* which lanes stand on an inner node, and whether to run at all */ \
+        "v_cmp_lt_i32_e32 vcc, -1, %[node]\n\t" \
+        "s_mov_b64 s[88:89], exec\n\t" \
+        "s_bcnt1_i32_b64 %[cnt], vcc\n\t" \
+        "s_cmp_ge_i32 %[cnt], %[thr]\n\t" \
+        "s_cbranch_scc1 4f\n\t" \
+        "s_cmp_eq_u32 %[cnt], 0\n\t" \
+        "s_cbranch_scc1 9f\n\t" \
+        "v_cmp_lt_u32_e64 s[90:91], %[sentinel], %[node]\n\t"  /* as unsigned: above the sentinel = a leaf */ \
+        "s_cmp_lg_u64 s[90:91], 0\n\t" \
+        "s_cbranch_scc1 9f\n\t" \
+        "4:\n\t" \
+        "s_mov_b64 exec, vcc\n\t" \
+        "ds_read_b128 v[" B "+8:" B "+11], %[node]\n\tds_read_b128 v[" B "+12:" B "+15], %[node] offset:" Q1 "\n\t" \
+        "1:\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t" \
+  /* x: r8 = centres (child 0 | child 1), r9 = half extents */ \
+        "v_fma_mix_f32 v[" B "+0], v[" B "+8], %[ix], %[ax] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t" \
+        "v_fma_mix_f32 v[" B "+1], v[" B "+8], %[ix], %[ax] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t" \
+        "v_fma_mix_f32 v[" B "+2], v[" B "+9], |%[ix]|, %[ex] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t" \
+        "v_fma_mix_f32 v[" B "+3], v[" B "+9], |%[ix]|, %[ex] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t" \
+        "v_pk_add_f32 v[" B "+4:" B "+5], v[" B "+0:" B "+1], v[" B "+2:" B "+3] neg_lo:[0,1] neg_hi:[0,1]\n\t"  /* near parameters */ \
+        "v_pk_add_f32 v[" B "+0:" B "+1], v[" B "+0:" B "+1], v[" B "+2:" B "+3]\n\t"  /* far parameters */ \
+  /* y: r10 = centres (child 0 | child 1), r11 = half extents */ \
+        "v_fma_mix_f32 v[" B "+2], v[" B "+10], %[iy], %[ay] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t" \
+        "v_fma_mix_f32 v[" B "+3], v[" B "+10], %[iy], %[ay] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t" \
+        "v_fma_mix_f32 v[" B "+8], v[" B "+11], |%[iy]|, %[ey] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t" \
+        "v_fma_mix_f32 v[" B "+9], v[" B "+11], |%[iy]|, %[ey] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t" \
+        "v_pk_add_f32 v[" B "+6:" B "+7], v[" B "+2:" B "+3], v[" B "+8:" B "+9] neg_lo:[0,1] neg_hi:[0,1]\n\t"  /* near parameters */ \
+        "v_pk_add_f32 v[" B "+2:" B "+3], v[" B "+2:" B "+3], v[" B "+8:" B "+9]\n\t"  /* far parameters */ \
+  /* z: r12 = centres (child 0 | child 1), r13 = half extents */ \
+        "v_fma_mix_f32 v[" B "+8], v[" B "+12], %[iz], %[az] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t" \
+        "v_fma_mix_f32 v[" B "+9], v[" B "+12], %[iz], %[az] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t" \
+        "v_fma_mix_f32 v[" B "+10], v[" B "+13], |%[iz]|, %[ez] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t" \
+        "v_fma_mix_f32 v[" B "+11], v[" B "+13], |%[iz]|, %[ez] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t" \
+        "v_pk_add_f32 v[" B "+12:" B "+13], v[" B "+8:" B "+9], v[" B "+10:" B "+11]\n\t"  /* far parameters */ \
+        "v_pk_add_f32 v[" B "+10:" B "+11], v[" B "+8:" B "+9], v[" B "+10:" B "+11] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"  /* near parameters, clamped to [0, 1]: max(., 0) for free */ \
+  /* near x / y / z = r4,117 / r6,119 / r10,123; far = r0,113 / r2,115 / r12,125 (child 0, child 1) */ \
+        "v_min_f32_e32 v[" B "+12], v[" B "+12], %[tmax]\n\t" \
+        "v_min_f32_e32 v[" B "+13], v[" B "+13], %[tmax]\n\t" \
+        "v_max3_f32 v[" B "+4], v[" B "+4], v[" B "+6], v[" B "+10]\n\t"  /* entry parameter of child 0 */ \
+        "v_min3_f32 v[" B "+0], v[" B "+0], v[" B "+2], v[" B "+12]\n\t"  /* exit parameter of child 0 */ \
+        "v_max3_f32 v[" B "+5], v[" B "+5], v[" B "+7], v[" B "+11]\n\t"  /* entry parameter of child 1 */ \
+        "v_min3_f32 v[" B "+1], v[" B "+1], v[" B "+3], v[" B "+13]\n\t"  /* exit parameter of child 1 */ \
+  /* r14, r15 = child links c0, c1 */ \
+        "v_cmp_le_f32_e64 s[90:91], v[" B "+4], v[" B "+0]\n\t"  /* h0 */ \
+        "v_cmp_le_f32_e64 s[92:93], v[" B "+5], v[" B "+1]\n\t"  /* h1 */ \
+        "v_cmp_lt_f32_e64 s[94:95], v[" B "+5], v[" B "+4]\n\t"  /* child 1 is entered first */ \
+        "s_or_b64 s[98:99], s[90:91], s[92:93]\n\t"  /* any */ \
+        "s_and_b64 s[94:95], s[94:95], s[92:93]\n\t" \
+        "s_andn2_b64 s[94:95], s[90:91], s[94:95]\n\t"  /* go to c0: h0 and not (h1 and child 1 first) */ \
+        "v_cndmask_b32_e64 v[" B "+7], v[" B "+15], v[" B "+14], s[94:95]\n\t" \
+        "v_cndmask_b32_e64 v[" B "+6], v[" B "+14], v[" B "+15], s[94:95]\n\t"  /* the other child, pushed where both are hit */ \
+        "v_cndmask_b32_e64 %[node], %[top], v[" B "+7], s[98:99]\n\t"  /* no child hit: go on with the stack top */ \
+  /* the stack: lanes without a hit child pop, lanes with two push the other one */ \
+        "s_andn2_b64 exec, exec, s[98:99]\n\t" \
+        "v_subrev_u32_e32 %[sp], %[stride], %[sp]\n\t" \
+        "ds_read_b32 %[top], %[sp]\n\t" \
+        "s_and_b64 exec, s[90:91], s[92:93]\n\t" \
+        "ds_write_b32 %[sp], %[top]\n\t" \
+        "v_add_u32_e32 %[sp], %[stride], %[sp]\n\t" \
+        "v_mov_b32_e32 %[top], v[" B "+6]\n\t" \
+  /* who goes on (lanes that left the loop earlier stand on a leaf or on the sentinel: negative either way) */ \
+        "s_mov_b64 exec, s[88:89]\n\t" \
+        "v_cmp_lt_i32_e32 vcc, -1, %[node]\n\t" \
+        "s_bcnt1_i32_b64 %[cnt], vcc\n\t" \
+        "s_mov_b64 exec, vcc\n\t" \
+        "ds_read_b128 v[" B "+8:" B "+11], %[node]\n\tds_read_b128 v[" B "+12:" B "+15], %[node] offset:" Q1 "\n\t" \
+        "s_cmp_ge_i32 %[cnt], %[thr]\n\t" \
+        "s_cbranch_scc1 1b\n\t" \
+  /* fewer than `thr` lanes go on: leave when none does, or when some lane of the wave waits at a leaf */ \
+        "s_cmp_eq_u32 %[cnt], 0\n\t" \
+        "s_cbranch_scc1 9f\n\t" \
+        "s_mov_b64 exec, s[88:89]\n\t" \
+        "v_cmp_lt_u32_e64 s[90:91], %[sentinel], %[node]\n\t" \
+        "s_mov_b64 exec, vcc\n\t" \
+        "s_cmp_lg_u64 s[90:91], 0\n\t" \
+        "s_cbranch_scc0 1b\n\t" \
+        "9:\n\t" \
+        "s_mov_b64 exec, s[88:89]\n\t" \
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+template <int BLOCK, bool LOW>
 __device__ __forceinline__ void inner_loop_lds16(Trav& T, int32_t thr) {
     static_assert(BLOCK == 512 || BLOCK == 256, "stack column stride");
     // the "s" operands must BE scalar registers: the constraint alone does not move a value the compiler holds in a
     // vector register (it would print v13 into an s_ instruction)
     thr = __builtin_amdgcn_readfirstlane(max(thr, 1));  // with 0 the loop would never see "no lane left"
     int32_t lanes_on_inner;
-    asm volatile(
-        // which lanes stand on an inner node, and whether to run at all
-        "v_cmp_lt_i32_e32 vcc, -1, %[node]\n\t"
-        "s_mov_b64 s[88:89], exec\n\t"
-        "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
-        "s_cmp_ge_i32 %[cnt], %[thr]\n\t"
-        "s_cbranch_scc1 4f\n\t"
-        "s_cmp_eq_u32 %[cnt], 0\n\t"
-        "s_cbranch_scc1 9f\n\t"
-        "v_cmp_lt_u32_e64 s[90:91], %[sentinel], %[node]\n\t"  // as unsigned: above the sentinel = a leaf
-        "s_cmp_lg_u64 s[90:91], 0\n\t"
-        "s_cbranch_scc1 9f\n\t"
-        "4:\n\t"
-        "s_mov_b64 exec, vcc\n\t"
-        RT_FETCH16
-        "1:\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        // x: v120 = centres (child 0 | child 1), v121 = half extents
-        "v_fma_mix_f32 v112, v120, %[ix], %[ax] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 v113, v120, %[ix], %[ax] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 v114, v121, |%[ix]|, %[ex] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 v115, v121, |%[ix]|, %[ex] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_pk_add_f32 v[116:117], v[112:113], v[114:115] neg_lo:[0,1] neg_hi:[0,1]\n\t"   // near parameters
-        "v_pk_add_f32 v[112:113], v[112:113], v[114:115]\n\t"   // far parameters
-        // y: v122 = centres (child 0 | child 1), v123 = half extents
-        "v_fma_mix_f32 v114, v122, %[iy], %[ay] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 v115, v122, %[iy], %[ay] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 v120, v123, |%[iy]|, %[ey] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 v121, v123, |%[iy]|, %[ey] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_pk_add_f32 v[118:119], v[114:115], v[120:121] neg_lo:[0,1] neg_hi:[0,1]\n\t"   // near parameters
-        "v_pk_add_f32 v[114:115], v[114:115], v[120:121]\n\t"   // far parameters
-        // z: v124 = centres (child 0 | child 1), v125 = half extents
-        "v_fma_mix_f32 v120, v124, %[iz], %[az] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 v121, v124, %[iz], %[az] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 v122, v125, |%[iz]|, %[ez] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 v123, v125, |%[iz]|, %[ez] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_pk_add_f32 v[124:125], v[120:121], v[122:123]\n\t"   // far parameters
-        "v_pk_add_f32 v[122:123], v[120:121], v[122:123] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"   // near parameters, clamped to [0, 1]: max(., 0) for free
-        // near x / y / z = v116,117 / v118,119 / v122,123; far = v112,113 / v114,115 / v124,125 (child 0, child 1)
-        "v_min_f32_e32 v124, v124, %[tmax]\n\t"
-        "v_min_f32_e32 v125, v125, %[tmax]\n\t"
-        "v_max3_f32 v116, v116, v118, v122\n\t"   // entry parameter of child 0
-        "v_min3_f32 v112, v112, v114, v124\n\t"   // exit parameter of child 0
-        "v_max3_f32 v117, v117, v119, v123\n\t"   // entry parameter of child 1
-        "v_min3_f32 v113, v113, v115, v125\n\t"   // exit parameter of child 1
-        // v126, v127 = child links c0, c1
-        "v_cmp_le_f32_e64 s[90:91], v116, v112\n\t"   // h0
-        "v_cmp_le_f32_e64 s[92:93], v117, v113\n\t"   // h1
-        "v_cmp_lt_f32_e64 s[94:95], v117, v116\n\t"   // child 1 is entered first
-        "s_or_b64 s[98:99], s[90:91], s[92:93]\n\t"   // any
-        "s_and_b64 s[94:95], s[94:95], s[92:93]\n\t"
-        "s_andn2_b64 s[94:95], s[90:91], s[94:95]\n\t"  // go to c0: h0 and not (h1 and child 1 first)
-        "v_cndmask_b32_e64 v119, v127, v126, s[94:95]\n\t"
-        "v_cndmask_b32_e64 v118, v126, v127, s[94:95]\n\t"  // the other child, pushed where both are hit
-        "v_cndmask_b32_e64 %[node], %[top], v119, s[98:99]\n\t"  // no child hit: go on with the stack top
-        // the stack: lanes without a hit child pop, lanes with two push the other one
-        "s_andn2_b64 exec, exec, s[98:99]\n\t"
-        "v_subrev_u32_e32 %[sp], %[stride], %[sp]\n\t"
-        "ds_read_b32 %[top], %[sp]\n\t"
-        "s_and_b64 exec, s[90:91], s[92:93]\n\t"
-        "ds_write_b32 %[sp], %[top]\n\t"
-        "v_add_u32_e32 %[sp], %[stride], %[sp]\n\t"
-        "v_mov_b32_e32 %[top], v118\n\t"
-        // who goes on (lanes that left the loop earlier stand on a leaf or on the sentinel: negative either way)
-        "s_mov_b64 exec, s[88:89]\n\t"
-        "v_cmp_lt_i32_e32 vcc, -1, %[node]\n\t"
-        "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
-        "s_mov_b64 exec, vcc\n\t"
-        RT_FETCH16
-        "s_cmp_ge_i32 %[cnt], %[thr]\n\t"
-        "s_cbranch_scc1 1b\n\t"
-        // fewer than `thr` lanes go on: leave when none does, or when some lane of the wave waits at a leaf
-        "s_cmp_eq_u32 %[cnt], 0\n\t"
-        "s_cbranch_scc1 9f\n\t"
-        "s_mov_b64 exec, s[88:89]\n\t"
-        "v_cmp_lt_u32_e64 s[90:91], %[sentinel], %[node]\n\t"
-        "s_mov_b64 exec, vcc\n\t"
-        "s_cmp_lg_u64 s[90:91], 0\n\t"
-        "s_cbranch_scc0 1b\n\t"
-        "9:\n\t"
-        "s_mov_b64 exec, s[88:89]\n\t"
-        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+    static_assert(kQ1Offset == 12288 && kQ1OffsetFive == 8192, "the offsets are spelled out below");
+    if constexpr (LOW) {
+        asm volatile(RT_LDS_LOOP("80", "8192")
         : [node] "+v"(T.node), [sp] "+v"(T.sp), [top] "+v"(T.top), [cnt] "=&s"(lanes_on_inner)
         : [ix] "v"(T.inv[0]), [iy] "v"(T.inv[1]), [iz] "v"(T.inv[2]), [ax] "v"(T.A[0]), [ay] "v"(T.A[1]),
           [az] "v"(T.A[2]), [ex] "v"(T.E[0]), [ey] "v"(T.E[1]), [ez] "v"(T.E[2]), [tmax] "v"(T.tmax),
           [thr] "s"(thr), [sentinel] "s"(kLeafSentinel), [stride] "s"(uint32_t(BLOCK * sizeof(int32_t)))
-        : "memory", "vcc", "scc", "v112", "v113", "v114", "v115", "v116", "v117",
-          "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "s88", "s89", "s90", "s91",
+        : "memory", "vcc", "scc", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "s88", "s89", "s90", "s91",
           "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
+    } else {
+        asm volatile(RT_LDS_LOOP("112", "12288")
+        : [node] "+v"(T.node), [sp] "+v"(T.sp), [top] "+v"(T.top), [cnt] "=&s"(lanes_on_inner)
+        : [ix] "v"(T.inv[0]), [iy] "v"(T.inv[1]), [iz] "v"(T.inv[2]), [ax] "v"(T.A[0]), [ay] "v"(T.A[1]),
+          [az] "v"(T.A[2]), [ex] "v"(T.E[0]), [ey] "v"(T.E[1]), [ez] "v"(T.E[2]), [tmax] "v"(T.tmax),
+          [thr] "s"(thr), [sentinel] "s"(kLeafSentinel), [stride] "s"(uint32_t(BLOCK * sizeof(int32_t)))
+        : "memory", "vcc", "scc", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "s88", "s89", "s90", "s91",
+          "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
+    }
+
 }
 
 #define RT_HBM_LOOP(B) \
@@ -1311,8 +1324,11 @@ constexpr int kModeProduction = 0, kModeStats = 1, kModeDump = 2, kModeTiming = 
 
 __device__ __forceinline__ uint64_t cycle_stamp() { return __builtin_amdgcn_s_memtime(); }
 // TREE = false is the kernel of scenes without a tree: the shade phase alone (every sphere is tested per segment).
-// FIVE = true (tree in HBM only): built for 96 vector registers, five waves per SIMD; chosen when five workgroups' stacks
-// fit the CU's LDS (resident_blocks).
+// FIVE = true: built for 96 vector registers, five waves per SIMD (256-thread workgroups, five to a CU); chosen when five
+// workgroups fit the CU's LDS (use_five_waves).  For a tree in LDS that build keeps only the nodes there (each
+// workgroup has its own copy: 8 KB + 16 bytes a node, next to its stacks) and reads spheres and material tables
+// through L1 like the HBM-tree kernel does; with the fifth wave the scalar and LDS instructions of one wave issue
+// beside the vector instructions of another more often (bench scene: 10.32 -> 9.9 ms).
 template <bool LDS16, int BLOCK, int MODE, bool TREE = true, bool FIVE = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FIVE ? 5 : 4, TREE ? (FIVE ? 5 : 4) : 8))) void render_kernel_ws(SceneDev S, CamDev C, RenderParams P,
                                                           const Node16* __restrict__ nodes16, uint32_t stack_depth,
@@ -1328,13 +1344,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FIVE ? 5 
     // (q1 begins kQ1Offset bytes after q0 whatever n_nodes is)
     const int32_t n_prims = S.n_spheres + S.n_discs, quads = (n_prims + 3) / 4;
     uint4* lds_q0 = lds_raw;
-    uint4* lds_q1 = lds_raw + (LDS16 ? kQ1Offset / 16 : 0);  // second halves at a fixed distance from the first (see inner_loop_lds16)
+    constexpr bool TABLES = LDS16 && !(TREE && FIVE);  // spheres and material tables staged in LDS too
+    uint4* lds_q1 = lds_raw + (LDS16 ? (FIVE ? kQ1OffsetFive : kQ1Offset) / 16 : 0);  // second halves at a fixed distance from the first (see inner_loop_lds16)
     uint4* lds_sph = lds_q1 + (LDS16 ? S.n_nodes : 0);
-    uint4* lds_mat = lds_sph + (LDS16 ? 2 * S.n_spheres : 0);
-    uint4* lds_kind = lds_mat + (LDS16 ? n_prims : 0);
-    uint4* lds_id = lds_kind + (LDS16 ? quads : 0);
-    uint4* lds_shell = lds_id + (LDS16 ? quads : 0);
-    int32_t* stk0 = reinterpret_cast<int32_t*>(lds_shell + ((LDS16 && S.shell_count > 0) ? kShellTable / 2 : 0));
+    uint4* lds_mat = lds_sph + (TABLES ? 2 * S.n_spheres : 0);
+    uint4* lds_kind = lds_mat + (TABLES ? n_prims : 0);
+    uint4* lds_id = lds_kind + (TABLES ? quads : 0);
+    uint4* lds_shell = lds_id + (TABLES ? quads : 0);
+    int32_t* stk0 = reinterpret_cast<int32_t*>(lds_shell + ((TABLES && S.shell_count > 0) ? kShellTable / 2 : 0));
     int32_t* stk = stk0 + threadIdx.x;
     lds_u32* wave_state = (lds_u32*)(reinterpret_cast<uint32_t*>(stk0 + stack_depth * BLOCK) + 4 * (threadIdx.x >> 6));
     wave_state[0] = blockIdx.x % kCounters; wave_state[1] = 64; wave_state[2] = 0; wave_state[3] = 0;
@@ -1353,6 +1370,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FIVE ? 5 
             lds_q0[i] = src[2 * i];
             lds_q1[i] = b;
         }
+    }
+    if (TABLES) {
         const uint4* ssrc = reinterpret_cast<const uint4*>(S.sph);
         for (int32_t i = threadIdx.x; i < 2 * S.n_spheres; i += BLOCK) lds_sph[i] = ssrc[i];
         const uint4* msrc = reinterpret_cast<const uint4*>(S.mat);
@@ -1365,7 +1384,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FIVE ? 5 
         if (S.shell_count > 0 && threadIdx.x < kShellTable) rdst[threadIdx.x] = S.shell_r2[threadIdx.x];
     }
     __syncthreads();
-    const Tables Tb = LDS16 ? Tables{reinterpret_cast<const double4*>(lds_sph), reinterpret_cast<const float4*>(lds_mat),
+    const Tables Tb = TABLES ? Tables{reinterpret_cast<const double4*>(lds_sph), reinterpret_cast<const float4*>(lds_mat),
                                      reinterpret_cast<const int32_t*>(lds_kind), reinterpret_cast<const int32_t*>(lds_id),
                                      reinterpret_cast<const double*>(lds_shell)}
                             : global_tables(S);
@@ -1498,7 +1517,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FIVE ? 5 
             const uint64_t t_inner = TIMING ? cycle_stamp() : 0;
             if (TIMING) cyc[1] += t_inner - t_head;
             if (LDS16 && !STATS) {
-                inner_loop_lds16<BLOCK>(T, run_threshold);
+                inner_loop_lds16<BLOCK, FIVE>(T, run_threshold);
             } else if (!STATS) {
                 inner_loop_hbm<BLOCK, FIVE>(T, S.nodes32, run_threshold);
             } else {
@@ -1679,6 +1698,7 @@ struct rt_scene {
     const Node16* d_nodes16 = nullptr;  // f16 copy of the nodes for the LDS-resident kernel (null when it has none)
     bool lds_scene = false;             // the render kernel stages nodes and primitive tables in LDS
     size_t lds16_scene_bytes = 0;
+    size_t lds16_five_bytes = 0;  // LDS the five-wave build stages for this scene (nodes only), 0 = the tree has too many nodes for it
     uint32_t stack_depth = 0;
     int n_cu = 0;
     double bound_abs = 0.0;  // largest |coordinate| of any box corner
@@ -1687,7 +1707,7 @@ struct rt_scene {
     // workgroups per CU of each render kernel variant for this scene's LDS footprint, 0 = not asked yet
     // ([0] lock-step kernel, [1 + mode] wave-scheduled kernel with the tree in HBM, [5 + mode] with the scene in LDS)
     int per_cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    int five_waves = -1;  // tree in HBM: 1 = the kernel built for five waves per SIMD is used, 0 = the four-wave one, -1 = not decided yet
+    int five_waves[2] = {-1, -1};  // [tree in HBM, tree in LDS]: 1 = the kernel built for five waves per SIMD is used, 0 = the four-wave one, -1 = not decided yet
 };
 
 namespace {
@@ -1796,8 +1816,8 @@ float descent_eps(const rt_scene* sc, double origin_abs) {
 size_t stack_bytes(const rt_scene* sc) { return size_t(std::max<uint32_t>(sc->stack_depth, 1u)) * kBlock * sizeof(int32_t) + 64 + kCamLdsBytes; }  // 16 bytes of hand-out state per wave, the camera
 
 // LDS of one workgroup of the LDS-resident kernel: scene tables, the stack columns of kBlockLds lanes, hand-out state
-size_t lds16_launch_bytes(size_t scene_bytes, uint32_t stack_depth) {
-    return scene_bytes + size_t(std::max<uint32_t>(stack_depth, 1u)) * kBlockLds * sizeof(int32_t) + 16 * (kBlockLds / 64) + kCamLdsBytes;
+size_t lds16_launch_bytes(size_t scene_bytes, uint32_t stack_depth, int block = kBlockLds) {
+    return scene_bytes + size_t(std::max<uint32_t>(stack_depth, 1u)) * size_t(block) * sizeof(int32_t) + 16 * size_t(block / 64) + kCamLdsBytes;
 }
 constexpr size_t kLdsPerCu = 160 * 1024;
 
@@ -1812,6 +1832,14 @@ struct DeviceGuard {
 
 typedef void (*ws_kernel_t)(SceneDev, CamDev, RenderParams, const Node16*, uint32_t, float*, float*, uint32_t*, float*);
 ws_kernel_t ws_kernel(bool lds16, int mode, bool tree = true, bool five = false) {
+    if (lds16 && tree && five) {
+        switch (mode) {
+        case kModeStats: return render_kernel_ws<true, kBlock, kModeStats, true, true>;
+        case kModeDump: return render_kernel_ws<true, kBlock, kModeDump, true, true>;
+        case kModeTiming: return render_kernel_ws<true, kBlock, kModeTiming, true, true>;
+        default: return render_kernel_ws<true, kBlock, kModeProduction, true, true>;
+        }
+    }
     if (!lds16 && five) {
         switch (mode) {
         case kModeStats: return render_kernel_ws<false, kBlock, kModeStats, true, true>;
@@ -1846,18 +1874,52 @@ ws_kernel_t ws_kernel(bool lds16, int mode, bool tree = true, bool five = false)
 
 // Workgroups per CU of one kernel variant for this scene (asked once per scene and variant, then remembered;
 // the production variant is asked when the scene is created, so a render call makes no query).
-// Tree in HBM: whether the scene runs the kernel built for five waves per SIMD (96 registers, a few of them spilled;
-// 1 M spheres: 24.9 -> 24.0 ms).  It does when five workgroups' traversal stacks fit the CU's LDS; a deeper tree keeps
-// the four-wave kernel, which has all its registers.
-int use_five_waves(rt_scene* sc, bool* five) {
-    if (sc->five_waves < 0) {
+// Whether the scene runs the build of its kernel made for five waves per SIMD (96 registers; 1 M spheres: 24.9 ->
+// 24.0 ms, bench scene 10.3 -> 9.9 ms).  It does when five of its 256-thread workgroups fit the CU's LDS: their
+// traversal stacks for a tree in HBM, stacks and a copy of the nodes each for a tree in LDS.  A deeper or larger tree
+// keeps the four-wave build, which has all its registers (and, in LDS, all its tables).
+int use_five_waves(rt_scene* sc, bool lds16, bool* five) {
+    int& state = sc->five_waves[lds16 ? 1 : 0];
+    if (state < 0) {
         int per_cu = 0;
-        RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ws_kernel(false, kModeProduction, true, true), kBlock, stack_bytes(sc)));
-        sc->five_waves = per_cu >= 5 ? 1 : 0;
-        if (const char* e = std::getenv("RT_HBM_FIVE_WAVES")) sc->five_waves = std::atoi(e) ? 1 : 0;  // tuning aid
+        if (!lds16) {
+            RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ws_kernel(false, kModeProduction, true, true), kBlock, stack_bytes(sc)));
+        } else if (sc->lds16_five_bytes != 0) {
+            const ws_kernel_t k = ws_kernel(true, kModeProduction, true, true);
+            RT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsPerCu / 2)));
+            RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, kBlock, lds16_launch_bytes(sc->lds16_five_bytes, sc->stack_depth, kBlock)));
+        }
+        state = per_cu >= 5 ? 1 : 0;
+        if (const char* e = std::getenv("RT_FIVE_WAVES")) state = (std::atoi(e) && (!lds16 || sc->lds16_five_bytes != 0)) ? 1 : 0;  // tuning aid
     }
-    *five = sc->five_waves == 1;
+    *five = state == 1;
     return RT_OK;
+}
+
+// Kernel, workgroup size and LDS bytes of a launch of the LDS-resident kernel for this scene.
+struct LdsLaunch {
+    ws_kernel_t kernel;
+    int block;
+    size_t lds;
+};
+int lds16_launch(rt_scene* sc, int mode, LdsLaunch* out) {
+    const bool tree = sc->dev.n_nodes != 0;
+    bool five = false;
+    if (tree) { if (int rc = use_five_waves(sc, true, &five)) return rc; }
+    out->kernel = ws_kernel(true, mode, tree, five);
+    // a scene without a tree runs the shade-only kernel: fewer registers, so 256-thread workgroups fill the SIMDs with
+    // five waves or more instead of four
+    out->block = (tree && !five) ? kBlockLds : kBlock;
+    out->lds = five ? lds16_launch_bytes(sc->lds16_five_bytes, sc->stack_depth, kBlock) : lds16_launch_bytes(sc->lds16_scene_bytes, sc->stack_depth);
+    return RT_OK;
+}
+
+// The work-item schedule of the scene's production kernel (make_params).  The choice of the build was made when the
+// scene was created (rt_scene_create asks for the production kernel's occupancy), so this only reads it.
+enum { kScheduleLds = 0, kScheduleHbm = 1, kScheduleLdsFive = 2 };
+int schedule_of(const rt_scene* sc) {
+    if (!sc->lds_scene) return kScheduleHbm;
+    return (sc->dev.n_nodes != 0 && sc->five_waves[1] == 1) ? kScheduleLdsFive : kScheduleLds;
 }
 
 int resident_blocks(rt_scene* sc, bool lockstep, bool lds16, int mode, int* out) {
@@ -1867,16 +1929,13 @@ int resident_blocks(rt_scene* sc, bool lockstep, bool lds16, int mode, int* out)
         if (lockstep) {
             RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel, kBlock, stack_bytes(sc)));
         } else if (lds16) {
-            const size_t lds = lds16_launch_bytes(sc->lds16_scene_bytes, sc->stack_depth);
-            // a scene without a tree runs the shade-only kernel: fewer registers, so 256-thread workgroups fill the
-            // SIMDs with five waves instead of four
-            const bool tree = sc->dev.n_nodes != 0;
-            const ws_kernel_t k = ws_kernel(true, mode, tree);
-            RT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsPerCu / 2)));
-            RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, tree ? kBlockLds : kBlock, lds));
+            LdsLaunch L;
+            if (int rc = lds16_launch(sc, mode, &L)) return rc;
+            RT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(L.kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsPerCu / 2)));
+            RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, L.kernel, L.block, L.lds));
         } else {
             bool five = false;
-            if (int rc = use_five_waves(sc, &five)) return rc;
+            if (int rc = use_five_waves(sc, false, &five)) return rc;
             RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ws_kernel(false, mode, true, five), kBlock, stack_bytes(sc)));
         }
         slot = per_cu < 1 ? 1 : per_cu;
@@ -1904,7 +1963,9 @@ uint32_t chunk_cap(const rt_camera& cam) {
     return uint32_t(std::min<uint64_t>(64, std::max<uint64_t>(1, uint64_t(RT_PARTIALS_BUDGET_BYTES) / std::max<uint64_t>(slot, 1))));
 }
 
-RenderParams make_params(const rt_camera& cam, const rt_render_opts& o, bool tree_in_hbm, uint32_t max_chunks = 0) {
+// schedule: how the library chooses the samples per work item for a scene (see below)
+RenderParams make_params(const rt_camera& cam, const rt_render_opts& o, int schedule, uint32_t max_chunks = 0) {
+    const bool tree_in_hbm = schedule == kScheduleHbm;
     if (max_chunks == 0) max_chunks = chunk_cap(cam);
     RenderParams P;
     P.sample_begin = o.sample_begin;
@@ -1931,7 +1992,10 @@ RenderParams make_params(const rt_camera& cam, const rt_render_opts& o, bool tre
         const uint32_t cap = std::max<uint32_t>(max_chunks, 1u);
         P.chunk_spp = std::min<uint32_t>(spp, std::max<uint32_t>(2u, (spp + cap - 1) / cap));
     } else {
-        const uint64_t want_items = 18000000, px = std::max<uint32_t>(P.n_pixels, 1);  // pixel chunks = 64 x tile items
+        // (the five-wave build has a quarter more waves to feed and does best with half as many items again: bench
+        // scene, chunks of 15 / 12 / 10 / 8 / 5 samples: 10.44 / 10.24 / 9.97 / 9.90 / 9.95 ms; 2160p/125 spp: 63 / 32 /
+        // 21 / 11 samples 47.3 / 46.9 / 46.9 / 47.5 ms)
+        const uint64_t want_items = schedule == kScheduleLdsFive ? 27000000 : 18000000, px = std::max<uint32_t>(P.n_pixels, 1);  // pixel chunks = 64 x tile items
         uint32_t chunks = uint32_t(std::min<uint64_t>(std::max<uint64_t>(1, (want_items + px / 2) / px), std::max<uint32_t>(max_chunks, 1u)));
         chunks = std::max<uint32_t>(1, std::min<uint32_t>(chunks, spp));
         P.chunk_spp = (spp + chunks - 1) / chunks;
@@ -2378,6 +2442,7 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
             if ((rc = upload(sc, n16, &sc->d_nodes16)) != RT_OK) return bail(rc);
             sc->lds16_scene_bytes = scene_bytes;
             sc->lds_scene = true;
+            if (n_nodes != 0 && 16 * n_nodes <= kQ1OffsetFive) sc->lds16_five_bytes = kQ1OffsetFive + 16 * n_nodes;
         }
     }
     {
@@ -2591,14 +2656,14 @@ int launch_render(rt_scene* scene, const rt_camera* cam, const rt_render_opts* o
                            d_sum_rgb, d_partials, d_work_counter);
     } else if (scene->lds_scene && !(opts->flags & RT_RENDER_KERNEL_NO_LDS_SCENE)) {
         if ((rc = resident_blocks(scene, false, true, mode, &per_cu)) != RT_OK) return rc;
-        const bool tree = scene->dev.n_nodes != 0;
-        hipLaunchKernelGGL(ws_kernel(true, mode, tree), grid_for(per_cu, tree ? kBlockLds : kBlock), dim3(tree ? kBlockLds : kBlock),
-                           lds16_launch_bytes(scene->lds16_scene_bytes, scene->stack_depth), st, S, C, P, scene->d_nodes16, depth_slots,
+        LdsLaunch L;
+        if ((rc = lds16_launch(scene, mode, &L)) != RT_OK) return rc;
+        hipLaunchKernelGGL(L.kernel, grid_for(per_cu, L.block), dim3(L.block), L.lds, st, S, C, P, scene->d_nodes16, depth_slots,
                            d_sum_rgb, d_partials, d_work_counter, d_dump);
     } else {
         if ((rc = resident_blocks(scene, false, false, mode, &per_cu)) != RT_OK) return rc;
         bool five = false;
-        if ((rc = use_five_waves(scene, &five)) != RT_OK) return rc;
+        if ((rc = use_five_waves(scene, false, &five)) != RT_OK) return rc;
         hipLaunchKernelGGL(ws_kernel(false, mode, true, five), grid_for(per_cu, kBlock), dim3(kBlock), stack_bytes(scene), st, S, C, P,
                            static_cast<const Node16*>(nullptr), depth_slots, d_sum_rgb, d_partials, d_work_counter, d_dump);
     }
@@ -2620,7 +2685,7 @@ int rt_scene_reserve(rt_scene* scene, const rt_camera* cam, const rt_render_opts
     if (rc != RT_OK) return rc;
     DeviceGuard guard;
     RT_HIP(hipSetDevice(scene->device));
-    return reserve_partials(scene, partials_needed(make_params(*cam, *opts, !scene->lds_scene)));
+    return reserve_partials(scene, partials_needed(make_params(*cam, *opts, schedule_of(scene))));
 }
 
 int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, float* d_sum_rgb, void* stream) {
@@ -2630,8 +2695,8 @@ int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_render_opts
     DeviceGuard guard;
     RT_HIP(hipSetDevice(scene->device));
     // grown on first use unless rt_scene_reserve has sized it (the one case in which this call waits and allocates)
-    if ((rc = reserve_partials(scene, partials_needed(make_params(*cam, *opts, !scene->lds_scene)))) != RT_OK) return rc;
-    return launch_render(scene, cam, opts, make_params(*cam, *opts, !scene->lds_scene), d_sum_rgb, static_cast<hipStream_t>(stream), scene->d_work_counter,
+    if ((rc = reserve_partials(scene, partials_needed(make_params(*cam, *opts, schedule_of(scene))))) != RT_OK) return rc;
+    return launch_render(scene, cam, opts, make_params(*cam, *opts, schedule_of(scene)), d_sum_rgb, static_cast<hipStream_t>(stream), scene->d_work_counter,
                          scene->d_partials, nullptr);
 }
 
@@ -2668,13 +2733,13 @@ int rt_render_device_noalloc(rt_scene* scene, const rt_camera* cam, const rt_ren
     static_assert(rt::kCounterBlockBytes <= 2048, "counter block inside the scratch header");
     constexpr size_t kHeader = 2048, kPartialBytes = size_t(RT_NOALLOC_SCRATCH_BYTES) - kHeader;
     const size_t slot = size_t(cam->horiz_res) * cam->vert_res * 3 * sizeof(float);
-    RenderParams P = make_params(*cam, *opts, !scene->lds_scene);
+    RenderParams P = make_params(*cam, *opts, schedule_of(scene));
     if (partials_needed(P) > kPartialBytes) {
         if (opts->samples_per_item)
             return fail(RT_ERR_LIMIT, "rt_render_device_noalloc: %u chunks of a %u x %u frame need %zu bytes of partial sums, the fixed scratch holds %zu",
                         P.n_chunks, cam->horiz_res, cam->vert_res, partials_needed(P), kPartialBytes);
         // chunk size left to the library: as many chunks as the scratch holds (one chunk needs no partial sums at all)
-        P = make_params(*cam, *opts, !scene->lds_scene, uint32_t(std::max<size_t>(kPartialBytes / slot, 1)));
+        P = make_params(*cam, *opts, schedule_of(scene), uint32_t(std::max<size_t>(kPartialBytes / slot, 1)));
     }
     return launch_render(scene, cam, opts, P, d_sum_rgb, static_cast<hipStream_t>(stream), reinterpret_cast<uint32_t*>(base),
                          reinterpret_cast<float*>(base + kHeader), nullptr);
@@ -2690,7 +2755,7 @@ int rt_debug_render_paths(rt_scene* scene, const rt_camera* cam, const rt_render
     const size_t n_pixels = size_t(cam->horiz_res) * cam->vert_res;
     const size_t n_paths = n_pixels * (opts->sample_end - opts->sample_begin);
     if (n_paths > (size_t(1) << 28)) return fail(RT_ERR_LIMIT, "rt_debug_render_paths: more than 2^28 paths in one call");
-    if ((rc = reserve_partials(scene, partials_needed(make_params(*cam, *opts, !scene->lds_scene)))) != RT_OK) return rc;
+    if ((rc = reserve_partials(scene, partials_needed(make_params(*cam, *opts, schedule_of(scene))))) != RT_OK) return rc;
     float *d_sum = nullptr, *d_dump = nullptr;
     RT_HIP(hipMalloc(reinterpret_cast<void**>(&d_sum), n_pixels * 3 * sizeof(float)));
     if (hipMalloc(reinterpret_cast<void**>(&d_dump), n_paths * 3 * sizeof(float)) != hipSuccess) {
@@ -2698,7 +2763,7 @@ int rt_debug_render_paths(rt_scene* scene, const rt_camera* cam, const rt_render
         return fail(RT_ERR_DEVICE, "rt_debug_render_paths: hipMalloc failed");
     }
     if (hipMemset(d_dump, 0, n_paths * 3 * sizeof(float)) != hipSuccess) rc = fail(RT_ERR_DEVICE, "rt_debug_render_paths: hipMemset failed");
-    if (rc == RT_OK) rc = launch_render(scene, cam, opts, make_params(*cam, *opts, !scene->lds_scene), d_sum, nullptr, scene->d_work_counter, scene->d_partials, d_dump);
+    if (rc == RT_OK) rc = launch_render(scene, cam, opts, make_params(*cam, *opts, schedule_of(scene)), d_sum, nullptr, scene->d_work_counter, scene->d_partials, d_dump);
     if (rc == RT_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(RT_ERR_DEVICE, "rt_debug_render_paths: kernel execution failed");
     if (rc == RT_OK && hipMemcpy(rgb, d_dump, n_paths * 3 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
         rc = fail(RT_ERR_DEVICE, "rt_debug_render_paths: download failed");
@@ -2710,7 +2775,7 @@ int rt_debug_render_paths(rt_scene* scene, const rt_camera* cam, const rt_render
 int rt_render_chunk(const rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, uint32_t* samples_per_item) {
     if (!scene || !cam || !opts || !samples_per_item) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_chunk: null argument");
     if (opts->sample_end <= opts->sample_begin) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_chunk: empty sample range");
-    *samples_per_item = make_params(*cam, *opts, !scene->lds_scene).chunk_spp;
+    *samples_per_item = make_params(*cam, *opts, schedule_of(scene)).chunk_spp;
     return RT_OK;
 }
 
@@ -2728,7 +2793,12 @@ int rt_debug_render_launch(rt_scene* scene, uint32_t* block_threads, uint32_t* w
     DeviceGuard guard;
     RT_HIP(hipSetDevice(scene->device));
     const bool lds16 = scene->lds_scene;
-    const int block = (lds16 && scene->dev.n_nodes != 0) ? kBlockLds : kBlock;  // the shade-only kernel of a scene without a tree runs 256-thread workgroups
+    int block = kBlock;
+    if (lds16) {
+        LdsLaunch L;
+        if (int rc = lds16_launch(scene, kModeProduction, &L)) return rc;
+        block = L.block;
+    }
     int per_cu = 0;
     if (int rc = resident_blocks(scene, false, lds16, kModeProduction, &per_cu)) return rc;
     *block_threads = uint32_t(block);
@@ -3073,7 +3143,7 @@ int rt_generate_primary(rt_scene* scene, const rt_camera* cam, uint64_t seed, ui
     if (hipMalloc(reinterpret_cast<void**>(&d_d), 3 * n * sizeof(float)) != hipSuccess) { (void)hipFree(d_o); return fail(RT_ERR_DEVICE, "rt_generate_primary: hipMalloc failed"); }
     rt_render_opts o{};
     o.sample_begin = sample_begin; o.sample_end = sample_end; o.depth = 1; o.flags = 0; o.seed = seed;
-    const RenderParams P = make_params(*cam, o, false);
+    const RenderParams P = make_params(*cam, o, kScheduleLds);
     hipLaunchKernelGGL(generate_primary_kernel, dim3(uint32_t((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr, make_cam(*cam), P,
                        pixel_begin, uint32_t(ns), uint32_t(n), d_o, d_d);
     int rc = RT_OK;
@@ -3134,12 +3204,12 @@ int rt_trace_path_segments(rt_scene* scene, const rt_camera* cam, const rt_rende
         const dim3 grid(uint32_t((n + kBlock - 1) / kBlock));
         if (rgb) {
             hipLaunchKernelGGL(trace_paths_kernel, grid, dim3(kBlock), stack_bytes(scene), nullptr, S, make_cam(*cam),
-                               make_params(*cam, o, false), d_p, d_s, uint32_t(n), d_rgb);
+                               make_params(*cam, o, kScheduleLds), d_p, d_s, uint32_t(n), d_rgb);
             chk(hipGetLastError(), "launch");
         }
         if (n_seg) {
             hipLaunchKernelGGL(path_segments_kernel, grid, dim3(kBlock), stack_bytes(scene), nullptr, S, make_cam(*cam),
-                               make_params(*cam, o, false), d_p, d_s, uint32_t(n), max_segments, d_sid, d_st, d_nseg);
+                               make_params(*cam, o, kScheduleLds), d_p, d_s, uint32_t(n), max_segments, d_sid, d_st, d_nseg);
             chk(hipGetLastError(), "launch");
         }
         chk(hipDeviceSynchronize(), "kernel");

@@ -780,7 +780,7 @@ def test_render_kernel_keeps_its_occupancy(rt, scene1):
 
     b, w, s = C.c_uint32(), C.c_uint32(), C.c_uint32()
     _abi.check(_abi.lib.rt_debug_render_launch(scene1.handle, C.byref(b), C.byref(w), C.byref(s)))
-    assert (b.value, w.value, s.value) == (512, 2, 4)
+    assert (b.value, w.value, s.value) == (256, 5, 5)  # the five-wave build: only the nodes in LDS, five workgroups to a CU
     big = rt.Scene(rt.gen_scene_grid(1, 60))  # 3601 spheres: too large for LDS
     assert big.info["lds_resident"] == 0
     _abi.check(_abi.lib.rt_debug_render_launch(big.handle, C.byref(b), C.byref(w), C.byref(s)))
@@ -791,6 +791,34 @@ def test_render_kernel_keeps_its_occupancy(rt, scene1):
     assert few.info["n_nodes"] == 0
     _abi.check(_abi.lib.rt_debug_render_launch(few.handle, C.byref(b), C.byref(w), C.byref(s)))
     assert b.value == 256 and w.value == s.value and s.value >= 5
+
+
+def test_four_and_five_wave_builds_render_the_same_image(rt, scene1):
+    """The kernel of a tree in LDS exists in two builds: five waves per SIMD with only the nodes in LDS (used when five
+    workgroups fit a CU), and four waves with spheres and material tables in LDS as well.  RT_FIVE_WAVES=0 when the
+    scene is created picks the second one; with the same samples per work item both must give the same bits."""
+    import ctypes as C
+    import os
+
+    from raytracer_amd import _abi
+
+    os.environ["RT_FIVE_WAVES"] = "0"
+    try:
+        four = rt.Scene(rt.gen_scene(1))
+    finally:
+        del os.environ["RT_FIVE_WAVES"]
+    b, w, s = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    _abi.check(_abi.lib.rt_debug_render_launch(four.handle, C.byref(b), C.byref(w), C.byref(s)))
+    assert (b.value, w.value, s.value) == (512, 2, 4)
+    _abi.check(_abi.lib.rt_debug_render_launch(scene1.handle, C.byref(b), C.byref(w), C.byref(s)))
+    assert (b.value, w.value, s.value) == (256, 5, 5)
+    cam = rt.default_camera(160, 96)
+    for chunk in (3, 7):
+        a, qa = four.render(cam, 7, depth=50, seed=11, samples_per_item=chunk)
+        c, qc = scene1.render(cam, 7, depth=50, seed=11, samples_per_item=chunk)
+        assert np.array_equal(a, c) and np.array_equal(qa, qc), chunk
+    # left to themselves the two builds cut a pixel's samples into different chunks
+    assert four.render_chunk(cam, 100) >= scene1.render_chunk(cam, 100)
 
 
 def test_wide_spheres_outside_the_tree(rt, ob):
