@@ -1919,7 +1919,9 @@ int lds16_launch(rt_scene* sc, int mode, LdsLaunch* out) {
 enum { kScheduleLds = 0, kScheduleHbm = 1, kScheduleLdsFive = 2 };
 int schedule_of(const rt_scene* sc) {
     if (!sc->lds_scene) return kScheduleHbm;
-    return (sc->dev.n_nodes != 0 && sc->five_waves[1] == 1) ? kScheduleLdsFive : kScheduleLds;
+    // (a scene without a tree runs the shade-only kernel at five or six waves and shares the five-wave schedule:
+    // nested shells, chunks of 12 / 8 / 6 samples: 10.43 / 10.22 / 10.14 ms)
+    return (sc->dev.n_nodes == 0 || sc->five_waves[1] == 1) ? kScheduleLdsFive : kScheduleLds;
 }
 
 int resident_blocks(rt_scene* sc, bool lockstep, bool lds16, int mode, int* out) {
