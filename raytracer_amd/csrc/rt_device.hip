@@ -1889,6 +1889,7 @@ int use_five_waves(rt_scene* sc, bool lds16, bool* five) {
             RT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsPerCu / 2)));
             RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, kBlock, lds16_launch_bytes(sc->lds16_five_bytes, sc->stack_depth, kBlock)));
         }
+        if (std::getenv("RT_CREATE_LAPS")) std::fprintf(stderr, "[use_five_waves] lds16 %d: %d workgroups per CU with %zu bytes of LDS\n", int(lds16), per_cu, lds16 ? lds16_launch_bytes(sc->lds16_five_bytes, sc->stack_depth, kBlock) : stack_bytes(sc));
         state = per_cu >= 5 ? 1 : 0;
         if (const char* e = std::getenv("RT_FIVE_WAVES")) state = (std::atoi(e) && (!lds16 || sc->lds16_five_bytes != 0)) ? 1 : 0;  // tuning aid
     }

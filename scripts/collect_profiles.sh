@@ -6,11 +6,11 @@ set -u
 out=$1
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout -s KILL 180 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --steps 5 --warmup 1 --cpu-seconds 0 > "$out/trace.log" 2>&1 || { echo "kernel trace failed"; tail -5 "$out/trace.log"; exit 1; }
+timeout -s KILL 180 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 > "$out/trace.log" 2>&1 || { echo "kernel trace failed"; tail -5 "$out/trace.log"; exit 1; }
 cp "$out"/trace/*/*kernel_stats.csv "$out/bench_kernel_stats.csv" 2>/dev/null
 bash scripts/pmc_passes.sh "$out/pmc" > "$out/pmc.log" 2>&1 || { echo "pmc failed"; tail -5 "$out/pmc.log"; exit 1; }
 cp "$out/pmc/summary.txt" "$out/bench_pmc_summary.txt"
-timeout -k 10 300 python3 bench.py > "$out/bench.log" 2>&1 || { echo "bench failed"; tail -5 "$out/bench.log"; exit 1; }
+timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > "$out/bench.log" 2>&1 || { echo "bench failed"; tail -5 "$out/bench.log"; exit 1; }
 tail -n 1 "$out/bench.log" > "$out/bench_line.json"
 : > "$out/configs.jsonl"; : > "$out/configs_with_phase_stats.jsonl"; : > "$out/configs_with_phase_timing.jsonl"
 for c in c1 c2 c2d10 c3 c4 c5 c6; do
