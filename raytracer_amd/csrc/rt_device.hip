@@ -1917,9 +1917,10 @@ int lds16_launch(rt_scene* sc, int mode, LdsLaunch* out) {
 
 // The work-item schedule of the scene's production kernel (make_params).  The choice of the build was made when the
 // scene was created (rt_scene_create asks for the production kernel's occupancy), so this only reads it.
-enum { kScheduleLds = 0, kScheduleHbm = 1, kScheduleLdsFive = 2 };
+enum { kScheduleLds = 0, kScheduleHbm = 1, kScheduleLdsFive = 2, kScheduleHbmBig = 3 };
 int schedule_of(const rt_scene* sc) {
-    if (!sc->lds_scene) return kScheduleHbm;
+    // a scene that does not fit the 256 MB Infinity Cache: see make_params
+    if (!sc->lds_scene) return sc->info.device_bytes > (size_t(256) << 20) ? kScheduleHbmBig : kScheduleHbm;
     // (a scene without a tree runs the shade-only kernel at five or six waves and shares the five-wave schedule:
     // nested shells, chunks of 12 / 8 / 6 samples: 10.43 / 10.22 / 10.14 ms)
     return (sc->dev.n_nodes == 0 || sc->five_waves[1] == 1) ? kScheduleLdsFive : kScheduleLds;
@@ -1968,7 +1969,7 @@ uint32_t chunk_cap(const rt_camera& cam) {
 
 // schedule: how the library chooses the samples per work item for a scene (see below)
 RenderParams make_params(const rt_camera& cam, const rt_render_opts& o, int schedule, uint32_t max_chunks = 0) {
-    const bool tree_in_hbm = schedule == kScheduleHbm;
+    const bool tree_in_hbm = schedule == kScheduleHbm || schedule == kScheduleHbmBig;
     if (max_chunks == 0) max_chunks = chunk_cap(cam);
     RenderParams P;
     P.sample_begin = o.sample_begin;
@@ -1993,7 +1994,10 @@ RenderParams make_params(const rt_camera& cam, const rt_render_opts& o, int sche
         P.chunk_spp = std::min<uint32_t>(o.samples_per_item, spp);
     } else if (tree_in_hbm) {
         const uint32_t cap = std::max<uint32_t>(max_chunks, 1u);
-        P.chunk_spp = std::min<uint32_t>(spp, std::max<uint32_t>(2u, (spp + cap - 1) / cap));
+        // (a scene larger than the Infinity Cache does best with single samples: 7.8 M spheres, chunks of 1 / 2 / 4:
+        // 7.93 / 8.30 / 9.41 ms; 1 M spheres, 1 / 2 / 3 / 4: 24.6 / 24.0 / 24.2 / 24.5)
+        const uint32_t least = schedule == kScheduleHbmBig ? 1u : 2u;
+        P.chunk_spp = std::min<uint32_t>(spp, std::max<uint32_t>(least, (spp + cap - 1) / cap));
     } else {
         // (the five-wave build has a quarter more waves to feed and does best with half as many items again: bench
         // scene, chunks of 15 / 12 / 10 / 8 / 5 samples: 10.44 / 10.24 / 9.97 / 9.90 / 9.95 ms; 2160p/125 spp: 63 / 32 /
