@@ -477,12 +477,16 @@ __device__ __forceinline__ bool hit_part(const SceneDev& S, const Tables& Tb, co
         return false;
     }
     const int32_t k = hit.k;
+    // the three table reads go out together, ahead of the arithmetic that does not need them
+    const int32_t kind_word = Tb.kind[k];
+    const float4 m = Tb.mat[k];
+    double4 s = make_double4(0.0, 0.0, 0.0, 1.0);
+    if (k < S.n_spheres) s = Tb.sph[k];  // (a disc's index lies beyond the sphere table, which may be empty)
     sf.hx = p.ox + hit.t * p.dx;  // scatter_loc = orig + t*dir (src/ray.rs:12-14)
     sf.hy = p.oy + hit.t * p.dy;
     sf.hz = p.oz + hit.t * p.dz;
     float lx, ly, lz;  // obj_relative_loc (src/lib.rs:106-113)
     if (k < S.n_spheres) {
-        const double4 s = Tb.sph[k];
         const float rx = float(sf.hx - s.x), ry = float(sf.hy - s.y), rz = float(sf.hz - s.z);
         const float inv_r = fast_rcp(float(s.w));
         sf.nx = rx * inv_r; sf.ny = ry * inv_r; sf.nz = rz * inv_r;  // src/geometry.rs:123-125
@@ -492,8 +496,6 @@ __device__ __forceinline__ bool hit_part(const SceneDev& S, const Tables& Tb, co
         sf.nx = float(dd.nx); sf.ny = float(dd.ny); sf.nz = float(dd.nz);  // src/geometry.rs:141-143
         lx = float(sf.hx - dd.cx); ly = float(sf.hy - dd.cy); lz = float(sf.hz - dd.cz);
     }
-    const int32_t kind_word = Tb.kind[k];
-    const float4 m = Tb.mat[k];
     sf.kind = kind_word & 0xff;
     sf.w = m.w;
     sf.ddn = fmaf(dzf, sf.nz, fmaf(dyf, sf.ny, dxf * sf.nx));
