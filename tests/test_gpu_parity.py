@@ -740,7 +740,7 @@ def test_random_scenes_across_size_thresholds(rt, ob):
     on the device (4095 / 4096).  Both builders: nearest hits against the oracle's scan over all spheres, and the
     render kernel's image against the ordered sum of the per-path entry point's colours."""
     rng = np.random.default_rng(7)
-    for n in (1, 2, 5, 6, 12, 13, 300, 1500, 4095, 4096, 6000):
+    for n in (1, 2, 5, 6, 12, 13, 300, 520, 1500, 4095, 4096, 6000):  # 300: five-wave build of the LDS kernel, 520: four-wave
         for giant in (False, True):
             scale = 10.0 ** rng.uniform(-2, 3)
             shift = rng.normal(0, 1, 3) * scale * 10.0 ** rng.uniform(-1, 2)
