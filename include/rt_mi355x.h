@@ -119,7 +119,11 @@ enum {
     RT_RENDER_KERNEL_NO_LDS_SCENE = 4, /* measurement aid: keep the BVH in HBM even when it would fit in LDS */
     RT_RENDER_STATS = 8,               /* measurement aid: instrumented kernel, see rt_debug_render_stats */
     RT_RENDER_TIMING = 16,             /* measurement aid: production kernel with a cycle stamp around each phase */
-    RT_RENDER_DEFER_LEAF = 32          /* measurement aid, with RT_RENDER_STATS: a lane puts its first leaf off and descends on */
+    RT_RENDER_DEFER_LEAF = 32,         /* measurement aid, with RT_RENDER_STATS: a lane puts its first leaf off and descends on */
+    RT_RENDER_KERNEL_WAVEFRONT = 64    /* the render as a pipeline of kernels (generate, then trace + shade per bounce) whose rays
+                                          meet in queues in device memory, compacted by the material they hit; same image bit
+                                          for bit, several times slower than the default persistent kernel; allocates a path pool
+                                          (104 bytes per path slot, at most 2^25 slots) on first use */
 };
 
 const char* rt_last_error(void);

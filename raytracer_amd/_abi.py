@@ -18,7 +18,7 @@ RT_ERR_INVALID_ARGUMENT, RT_ERR_UNSUPPORTED, RT_ERR_DEVICE, RT_ERR_IO, RT_ERR_LI
 RT_SHAPE_SPHERE, RT_SHAPE_DISC = 0, 1
 RT_MAT_DIFFUSE, RT_MAT_METAL, RT_MAT_DIELECTRIC, RT_MAT_TEXTUREMAP, RT_MAT_EMITTER = 0, 1, 2, 3, 4
 RT_RENDER_ACCUMULATE, RT_RENDER_KERNEL_LOCKSTEP, RT_RENDER_KERNEL_NO_LDS_SCENE = 1, 2, 4
-RT_RENDER_STATS, RT_RENDER_TIMING, RT_RENDER_DEFER_LEAF = 8, 16, 32
+RT_RENDER_STATS, RT_RENDER_TIMING, RT_RENDER_DEFER_LEAF, RT_RENDER_KERNEL_WAVEFRONT = 8, 16, 32, 64
 RT_NOALLOC_SCRATCH_BYTES = 64 * 1024 * 1024
 
 # rt_hittable as a numpy record (same layout as the C struct), so that a million

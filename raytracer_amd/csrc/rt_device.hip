@@ -1674,6 +1674,234 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const float* __restric
     rgb8[g] = q;
 }
 
+// ---------------------------------------------------------------- wavefront renderer (RT_RENDER_KERNEL_WAVEFRONT)
+// The same path tracer as a pipeline of kernels that hand rays to one another through queues in HBM, with the rays
+// compacted by the material they hit: generate -> for every bounce { trace: nearest hit of every queued ray, the ray's
+// slot appended to the queue of its hit's material class; shade: one wave works on rays of ONE class (miss or emitter /
+// diffuse or texture map / metal / dielectric), ends the path or scatters it and appends the survivor to the next
+// bounce's ray queue } -> accumulate.  A path lives in one slot of a pool for its whole life (slot = pixel in batch *
+// samples + sample), a queue holds slot numbers, and a frame larger than the pool is rendered in batches of whole
+// pixels.  Every path is traced with the arithmetic of the persistent kernel (same Philox counters, same functions),
+// and a pixel's samples are added in the same order and chunk grouping, so the image equals render_kernel_ws's bit
+// for bit.  Measured against it on the bench scene the pipeline is several times slower (each segment writes and
+// reads its ray, hit and throughput through HBM and every bounce costs two launches): it is kept as the measured
+// alternative, not as the default.
+struct WfState {
+    double* ray;       // 6 per slot: origin, unit direction
+    float* thr;        // 3 per slot: throughput
+    double* hit_t;     // per slot: parameter of the nearest hit of the segment being shaded
+    int32_t* hit_k;    // per slot: its table index, -1 = miss
+    float* colour;     // 3 per slot: what the finished path contributes
+    uint32_t* rayq;    // kWfSub sub-queues of sub_cap slots: the rays whose next segment is to be traced
+    uint32_t* matq;    // kWfClasses x kWfSub sub-queues: the traced rays by class of the material they hit
+    uint32_t* counts;  // queue lengths, see wf_count
+    uint32_t sub_cap;
+};
+constexpr int kWfClasses = 4;  // 0 miss / emitter (the path ends), 1 diffuse / texture map, 2 metal, 3 dielectric
+// A queue is kWfSub sub-queues with a length word each, every word on a cache line of its own: a workgroup appends
+// to sub-queue (its number mod kWfSub).  One length word per queue was the bottleneck of the whole pipeline (a word
+// serves about 90 atomics per microsecond; a 1080p / 100 spp frame makes 13 M wave-level appends per queue).
+constexpr int kWfSub = 16;
+constexpr uint32_t kWfMaxSlots = 1u << 25;
+// A sub-queue receives what the workgroups of one residue class produce, at most 1 / kWfSub of the entries plus one
+// 64-entry block per wave of the grid: room for that share and 65536 entries more.
+constexpr uint32_t kWfSubMargin = 65536;
+constexpr uint32_t kWfCountWords = 32;  // words between two length words (128 bytes)
+constexpr uint32_t kWfCountsPerBounce = (1 + kWfClasses) * kWfSub * kWfCountWords;
+// length word of sub-queue `sub` of queue q (0 = rays to trace, 1 + c = class c to shade) of bounce b; the very last
+// word block of the array (bounce depth + 1) is an overflow flag
+__device__ __forceinline__ uint32_t* wf_count(const WfState& W, uint32_t bounce, uint32_t q, uint32_t sub) {
+    return W.counts + size_t(bounce) * kWfCountsPerBounce + (q * kWfSub + sub) * kWfCountWords;
+}
+
+// position of each asking lane in a sub-queue: one atomic per wave
+__device__ __forceinline__ uint32_t wf_append(uint32_t* count, bool ask) {
+    const unsigned long long m = __ballot(ask);
+    if (m == 0) return 0;
+    const int first = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (int(__lane_id()) == first) base = atomicAdd(count, uint32_t(__popcll(m)));
+    base = uint32_t(__builtin_amdgcn_readlane(int32_t(base), first));
+    return base + __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+}
+
+// The sub-queues of a bounce's input, each rounded up to whole 64-entry blocks, laid end to end: ends[i] = end of
+// segment i in that index space (n_seg <= kWfClasses * kWfSub).  Called by the whole workgroup.
+__device__ __forceinline__ void wf_segments(const WfState& W, uint32_t bounce, uint32_t q_first, uint32_t n_seg, uint32_t* len, uint32_t* ends) {
+    if (threadIdx.x < n_seg) len[threadIdx.x] = min(*wf_count(W, bounce, q_first + threadIdx.x / kWfSub, threadIdx.x % kWfSub), W.sub_cap);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t i = 0; i < n_seg; ++i) { total += (len[i] + 63u) & ~63u; ends[i] = total; }
+    }
+    __syncthreads();
+}
+// segment of the 64-entry block that begins at g0 (g0 < ends[n_seg - 1])
+__device__ __forceinline__ uint32_t wf_segment_of(const uint32_t* ends, uint32_t n_seg, uint32_t g0) {
+    uint32_t lo = 0, hi = n_seg - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (g0 < ends[mid]) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(kBlock) void wf_generate_kernel(CamDev C, RenderParams P, WfState W, uint32_t pixel0, uint32_t n_paths) {
+    const uint32_t spp = P.sample_end - P.sample_begin;
+    const uint32_t per = (((n_paths + kWfSub - 1) / kWfSub) + 63u) & ~63u;  // paths per sub-queue
+    for (uint32_t g = blockIdx.x * kBlock + threadIdx.x; g < n_paths; g += gridDim.x * kBlock) {
+        if (g < uint32_t(kWfSub)) *wf_count(W, 0, 0, g) = (P.depth == 0 || g * per >= n_paths) ? 0u : min(per, n_paths - g * per);
+        if (P.depth == 0) { W.colour[3 * size_t(g)] = 1.0f; W.colour[3 * size_t(g) + 1] = 1.0f; W.colour[3 * size_t(g) + 2] = 1.0f; continue; }
+        Path p;
+        start_path(C, P, pixel0 + g / spp, P.sample_begin + g % spp, p);
+        double* r = W.ray + 6 * size_t(g);
+        r[0] = p.ox; r[1] = p.oy; r[2] = p.oz; r[3] = p.dx; r[4] = p.dy; r[5] = p.dz;
+        W.thr[3 * size_t(g)] = 1.0f; W.thr[3 * size_t(g) + 1] = 1.0f; W.thr[3 * size_t(g) + 2] = 1.0f;
+        W.rayq[size_t(g / per) * W.sub_cap + g % per] = g;
+    }
+}
+
+// Nearest hit of every queued ray: the descent of render_kernel_ws (assembly inner loops, f64 sphere test) on 64 rays
+// per wave at a time, then the compaction: the ray's slot goes to the queue of its hit's material class.
+template <bool LDS16>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) void wf_trace_kernel(SceneDev S, RenderParams P, WfState W,
+                                                                                                 const Node16* __restrict__ nodes16, uint32_t bounce) {
+    extern __shared__ uint4 lds_raw[];
+    uint4* lds_q0 = lds_raw;
+    uint4* lds_q1 = lds_raw + (LDS16 ? kQ1OffsetFive / 16 : 0);
+    int32_t* stk0 = reinterpret_cast<int32_t*>(lds_q1 + (LDS16 ? S.n_nodes : 0));
+    int32_t* stk = stk0 + threadIdx.x;
+    stk[0] = kLeafSentinel;
+    __shared__ uint32_t seg_len[kWfSub], seg_end[kWfSub];
+    if (LDS16) {
+        const uint4* src = reinterpret_cast<const uint4*>(nodes16);
+        const uint32_t q0_base = lds_address(lds_q0);
+        for (int32_t i = threadIdx.x; i < S.n_nodes; i += kBlock) {
+            uint4 b = src[2 * i + 1];
+            if (int32_t(b.z) >= 0) b.z += q0_base;
+            if (int32_t(b.w) >= 0) b.w += q0_base;
+            lds_q0[i] = src[2 * i];
+            lds_q1[i] = b;
+        }
+    }
+    wf_segments(W, bounce, 0, kWfSub, seg_len, seg_end);
+    const Tables Tb = global_tables(S);
+    const uint32_t q0_addr = lds_address(lds_q0);
+    const uint32_t slot1_addr = lds_address(stk) + uint32_t(kBlock * sizeof(int32_t));
+    const uint32_t total = seg_end[kWfSub - 1];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t waves = gridDim.x * (kBlock / 64);
+    const uint32_t my_sub = blockIdx.x % kWfSub;
+    for (uint32_t g0 = (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 64u; g0 < total; g0 += waves * 64u) {
+        const uint32_t seg = wf_segment_of(seg_end, kWfSub, g0);
+        const uint32_t j = g0 - (seg ? seg_end[seg - 1] : 0u) + lane;
+        const bool active = j < seg_len[seg];
+        const uint32_t slot = active ? W.rayq[size_t(seg) * W.sub_cap + j] : 0u;
+        const double* r = W.ray + 6 * size_t(slot);
+        Path p;
+        p.ox = r[0]; p.oy = r[1]; p.oz = r[2]; p.dx = r[3]; p.dy = r[4]; p.dz = r[5];
+        p.tr = p.tg = p.tb = 0.0f; p.pixel = p.sample = p.bounce = 0;
+        Trav T;
+        trav_begin<!LDS16, true>(S, Tb, p, T, slot1_addr, LDS16 ? int32_t(q0_addr) : 0);
+        if (!active) T.node = kLeafSentinel;
+        while (__any(T.node != kLeafSentinel)) {
+            if constexpr (LDS16) inner_loop_lds16<kBlock, true>(T, int32_t(P.inner_threshold));
+            else inner_loop_hbm<kBlock, true>(T, S.nodes32, int32_t(P.inner_threshold));
+            if (T.node < 0 && T.node != kLeafSentinel) leaf_step<LDS16, kBlock>(Tb, p, T, S.t_scale);
+        }
+        int32_t cls = 0;
+        if (active) {
+            W.hit_t[slot] = T.best.t;
+            W.hit_k[slot] = T.best.k;
+            if (T.best.k >= 0) {
+                const int32_t kind = Tb.kind[T.best.k] & 0xff;
+                cls = kind == RT_MAT_METAL ? 2 : kind == RT_MAT_DIELECTRIC ? 3 : kind == RT_MAT_EMITTER ? 0 : 1;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < kWfClasses; ++c) {
+            const bool mine = active && cls == c;
+            const uint32_t pos = wf_append(wf_count(W, bounce, 1 + c, my_sub), mine);
+            if (mine) {
+                if (pos < W.sub_cap) W.matq[(size_t(c) * kWfSub + my_sub) * W.sub_cap + pos] = slot;
+                else *wf_count(W, P.depth + 1, 0, 0) = 1u;  // cannot happen by the sizing of the sub-queues; never write past one
+            }
+        }
+    }
+}
+
+// One bounce of shading.  The class queues are walked one after the other, each sub-queue rounded up to whole waves,
+// so the lanes of a wave work on hits of one material class.
+__global__ __launch_bounds__(kBlock) void wf_shade_kernel(SceneDev S, RenderParams P, WfState W, uint32_t pixel0, uint32_t bounce) {
+    __shared__ uint32_t seg_len[kWfClasses * kWfSub], seg_end[kWfClasses * kWfSub];
+    constexpr uint32_t n_seg = kWfClasses * kWfSub;
+    static_assert(n_seg <= uint32_t(kBlock), "one thread per segment");
+    wf_segments(W, bounce, 1, n_seg, seg_len, seg_end);
+    const Tables Tb = global_tables(S);
+    const uint32_t spp = P.sample_end - P.sample_begin;
+    const uint32_t total = seg_end[n_seg - 1];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t waves = gridDim.x * (kBlock / 64);
+    const uint32_t my_sub = blockIdx.x % kWfSub;
+    for (uint32_t g0 = (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 64u; g0 < total; g0 += waves * 64u) {
+        const uint32_t seg = wf_segment_of(seg_end, n_seg, g0);
+        const uint32_t j = g0 - (seg ? seg_end[seg - 1] : 0u) + lane;
+        bool alive = false;
+        uint32_t slot = 0;
+        if (j < seg_len[seg]) {
+            slot = W.matq[size_t(seg) * W.sub_cap + j];
+            double* r = W.ray + 6 * size_t(slot);
+            float* th = W.thr + 3 * size_t(slot);
+            Path p;
+            p.ox = r[0]; p.oy = r[1]; p.oz = r[2]; p.dx = r[3]; p.dy = r[4]; p.dz = r[5];
+            p.tr = th[0]; p.tg = th[1]; p.tb = th[2];
+            p.pixel = pixel0 + slot / spp; p.sample = P.sample_begin + slot % spp; p.bounce = bounce + 1;
+            Best hit;
+            hit.t = W.hit_t[slot]; hit.k = W.hit_k[slot]; hit.id = 0;
+            Surf sf;
+            float Lr, Lg, Lb;
+            alive = hit_part(S, Tb, P, p, hit, sf, Lr, Lg, Lb);
+            float d[3] = {0.0f, 0.0f, 0.0f};
+            if (alive) {
+                const uint4 rnd = philox4x32_10(p.pixel, p.sample, p.bounce, 0u, P.key0, P.key1);
+                alive = scatter_raw(P, p, sf, rnd, d[0], d[1], d[2]);
+                if (!alive) { Lr = Lg = Lb = 0.0f; }  // the bounded fuzz loop gave up: the path contributes nothing
+            }
+            if (alive) {
+                normalize3(d[0], d[1], d[2]);
+                double dx, dy, dz;
+                unit_f64(d[0], d[1], d[2], &dx, &dy, &dz);
+                r[0] = sf.hx; r[1] = sf.hy; r[2] = sf.hz; r[3] = dx; r[4] = dy; r[5] = dz;
+                th[0] = p.tr; th[1] = p.tg; th[2] = p.tb;
+            } else {
+                float* o = W.colour + 3 * size_t(slot);
+                o[0] = Lr; o[1] = Lg; o[2] = Lb;
+            }
+        }
+        const uint32_t pos = wf_append(wf_count(W, bounce + 1, 0, my_sub), alive);
+        if (alive) {
+            if (pos < W.sub_cap) W.rayq[size_t(my_sub) * W.sub_cap + pos] = slot;
+            else *wf_count(W, P.depth + 1, 0, 0) = 1u;
+        }
+    }
+}
+
+// A pixel's colours added in sample order, chunk by chunk, into the places render_kernel_ws's flush_item writes.
+__global__ __launch_bounds__(kBlock) void wf_accumulate_kernel(RenderParams P, WfState W, uint32_t pixel0, uint32_t n_batch_pixels,
+                                                               float* __restrict__ sum_rgb, float* __restrict__ partials) {
+    const uint32_t spp = P.sample_end - P.sample_begin;
+    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
+    if (g >= n_batch_pixels * P.n_chunks) return;
+    const uint32_t chunk = g / n_batch_pixels, pl = g - chunk * n_batch_pixels;
+    const uint32_t s0 = chunk * P.chunk_spp, s1 = min(s0 + P.chunk_spp, spp);
+    float ar = 0.0f, ag = 0.0f, ab = 0.0f;
+    for (uint32_t s = s0; s < s1; ++s) {
+        const float* c = W.colour + 3 * (size_t(pl) * spp + s);
+        ar += c[0]; ag += c[1]; ab += c[2];
+    }
+    flush_item(P, sum_rgb, partials, pixel0 + pl, chunk, ar, ag, ab);
+}
+
 // Scratch of rt_render_device_noalloc: the first 2048 bytes are the counter block (the words of the diagnostic
 // builds and the work counters), the rest holds the partial sums of chunked renders.  One copy per GPU the library runs on, for the life of
 // the process.  In host code this name is only a handle for hipGetSymbolAddress, never a device address.
@@ -1693,6 +1921,10 @@ struct rt_scene {
     std::vector<void*> allocations;
     uint32_t* d_work_counter = nullptr;
     float* d_partials = nullptr;        // partial-sum slots of chunked renders, grown on demand
+    unsigned char* d_wf = nullptr;      // path pool and queues of the wavefront renderer (RT_RENDER_KERNEL_WAVEFRONT), made on first use
+    size_t wf_slots = 0;
+    uint32_t* d_wf_counts = nullptr;    // its queue lengths, eight words per bounce
+    size_t wf_counts_bytes = 0;
     float* d_frame_sum = nullptr;       // frame buffers of rt_render (host-buffer entry point), kept between calls
     uint8_t* d_frame_rgb = nullptr;
     size_t frame_pixels = 0;
@@ -2070,6 +2302,8 @@ void rt_scene_destroy(rt_scene* scene) {
     (void)hipSetDevice(scene->device);
     if (scene->ev_done) { (void)hipEventSynchronize(scene->ev_done); (void)hipEventDestroy(scene->ev_done); }
     if (scene->d_partials) (void)hipFree(scene->d_partials);
+    if (scene->d_wf) (void)hipFree(scene->d_wf);
+    if (scene->d_wf_counts) (void)hipFree(scene->d_wf_counts);
     if (scene->d_frame_sum) (void)hipFree(scene->d_frame_sum);
     if (scene->d_frame_rgb) (void)hipFree(scene->d_frame_rgb);
     for (void* p : scene->allocations) (void)hipFree(p);
@@ -2630,6 +2864,74 @@ size_t partials_needed(const RenderParams& P) {
     return P.n_chunks > 1 ? size_t(P.n_chunks) * P.n_pixels * 3 * sizeof(float) : 0;
 }
 
+// RT_RENDER_KERNEL_WAVEFRONT: the render as a pipeline of kernels with queues in HBM (see wf_trace_kernel).  The pool
+// of path slots belongs to the scene and is made on first use (104 bytes per slot, at most 2^25 slots = 3.5 GB); a
+// frame with more paths is rendered in batches of whole pixels.  Per batch: one generate, depth x (trace + shade), one
+// accumulate; nothing comes back to the host in between (empty queues cost their launches).
+int launch_wavefront(rt_scene* scene, const SceneDev& S, const CamDev& C, const RenderParams& P, float* d_sum_rgb, hipStream_t st,
+                     float* d_partials) {
+    const uint32_t spp = P.sample_end - P.sample_begin;
+    uint32_t max_slots = kWfMaxSlots;
+    if (const char* e = std::getenv("RT_WF_SLOTS")) max_slots = uint32_t(std::min<long long>(std::max<long long>(std::atoll(e), 1), kWfMaxSlots));  // test aid: small pools, many batches
+    if (spp > max_slots) return fail(RT_ERR_LIMIT, "wavefront render: %u samples per pixel exceed the pool of %u path slots", spp, max_slots);
+    const uint64_t n_paths = uint64_t(P.n_pixels) * spp;
+    const size_t slots = size_t(std::min<uint64_t>(n_paths, (max_slots / spp) * uint64_t(spp)));
+    const size_t count_bytes = (size_t(P.depth) + 2) * kWfCountsPerBounce * sizeof(uint32_t);
+    const size_t sub_cap = (slots + kWfSub - 1) / kWfSub + kWfSubMargin;
+    const size_t pool_bytes = slots * (48 + 8 + 12 + 12 + 4) + (1 + kWfClasses) * kWfSub * sub_cap * sizeof(uint32_t) + 256;
+    if (scene->wf_slots < slots || !scene->d_wf) {
+        RT_HIP(hipEventSynchronize(scene->ev_done));
+        if (scene->d_wf) { (void)hipFree(scene->d_wf); scene->d_wf = nullptr; scene->wf_slots = 0; }
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_wf), pool_bytes));
+        scene->wf_slots = slots;
+    }
+    if (count_bytes > scene->wf_counts_bytes) {
+        RT_HIP(hipEventSynchronize(scene->ev_done));
+        if (scene->d_wf_counts) { (void)hipFree(scene->d_wf_counts); scene->d_wf_counts = nullptr; scene->wf_counts_bytes = 0; }
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_wf_counts), count_bytes));
+        scene->wf_counts_bytes = count_bytes;
+    }
+    WfState W;
+    unsigned char* base = scene->d_wf;
+    const size_t cap = scene->wf_slots;
+    const size_t pool_sub_cap = (cap + kWfSub - 1) / kWfSub + kWfSubMargin;  // of the pool as it was made (it may be larger than this frame needs)
+    W.ray = reinterpret_cast<double*>(base); base += cap * 48;
+    W.hit_t = reinterpret_cast<double*>(base); base += cap * 8;
+    W.thr = reinterpret_cast<float*>(base); base += cap * 12;
+    W.colour = reinterpret_cast<float*>(base); base += cap * 12;
+    W.hit_k = reinterpret_cast<int32_t*>(base); base += cap * 4;
+    W.rayq = reinterpret_cast<uint32_t*>(base); base += size_t(kWfSub) * pool_sub_cap * 4;
+    W.matq = reinterpret_cast<uint32_t*>(base);
+    W.counts = scene->d_wf_counts;
+    W.sub_cap = uint32_t(pool_sub_cap);
+    (void)sub_cap;
+    const bool lds16 = scene->lds_scene && scene->dev.n_nodes != 0 && scene->lds16_five_bytes != 0;
+    const size_t trace_lds = lds16 ? lds16_launch_bytes(scene->lds16_five_bytes, scene->stack_depth, kBlock) - kCamLdsBytes : stack_bytes(scene);
+    if (lds16) RT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_trace_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsPerCu / 2)));
+    const uint32_t batch_pixels = uint32_t(slots / spp);
+    for (uint32_t pixel0 = 0; pixel0 < P.n_pixels; pixel0 += batch_pixels) {
+        const uint32_t npix = std::min<uint32_t>(batch_pixels, P.n_pixels - pixel0);
+        const uint32_t n = npix * spp;
+        // (grids are multiples of kWfSub, so that every sub-queue gets the output of the same number of workgroups)
+        auto grid_of = [&](uint64_t per_cu) {
+            const uint64_t g = std::min<uint64_t>((uint64_t(n) + kBlock - 1) / kBlock, uint64_t(scene->n_cu) * per_cu);
+            return uint32_t((g + kWfSub - 1) / kWfSub * kWfSub);
+        };
+        const uint32_t full = grid_of(8), trace_grid = grid_of(5);
+        RT_HIP(hipMemsetAsync(W.counts, 0, count_bytes, st));
+        hipLaunchKernelGGL(wf_generate_kernel, dim3(full), dim3(kBlock), 0, st, C, P, W, pixel0, n);
+        for (uint32_t b = 0; b < P.depth; ++b) {
+            if (lds16) hipLaunchKernelGGL(wf_trace_kernel<true>, dim3(trace_grid), dim3(kBlock), trace_lds, st, S, P, W, scene->d_nodes16, b);
+            else hipLaunchKernelGGL(wf_trace_kernel<false>, dim3(trace_grid), dim3(kBlock), trace_lds, st, S, P, W, static_cast<const Node16*>(nullptr), b);
+            hipLaunchKernelGGL(wf_shade_kernel, dim3(full), dim3(kBlock), 0, st, S, P, W, pixel0, b);
+        }
+        const uint32_t n_acc = npix * P.n_chunks;
+        hipLaunchKernelGGL(wf_accumulate_kernel, dim3((n_acc + kBlock - 1) / kBlock), dim3(kBlock), 0, st, P, W, pixel0, npix, d_sum_rgb, d_partials);
+        RT_HIP(hipGetLastError());
+    }
+    return RT_OK;
+}
+
 // The body of rt_render_device.  work_counter / partials: the scene's own, or the caller's (the entry point that
 // allocates nothing brings its own).  d_dump: per-path colours of the kModeDump build, else null.
 int launch_render(rt_scene* scene, const rt_camera* cam, const rt_render_opts* opts, const RenderParams& P, float* d_sum_rgb,
@@ -2659,7 +2961,12 @@ int launch_render(rt_scene* scene, const rt_camera* cam, const rt_render_opts* o
     else if (opts->flags & RT_RENDER_TIMING) mode = kModeTiming;
     const uint32_t depth_slots = std::max<uint32_t>(scene->stack_depth, 1u);
     int per_cu = 0, rc;
-    if ((opts->flags & RT_RENDER_KERNEL_LOCKSTEP) && !d_dump) {
+    if ((opts->flags & RT_RENDER_KERNEL_WAVEFRONT) && mode == kModeProduction) {
+        if (d_work_counter != scene->d_work_counter)
+            return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_device_noalloc: the wavefront renderer keeps its path pool in memory of its own");
+        if (capturing) return fail(RT_ERR_INVALID_ARGUMENT, "wavefront render: the path pool cannot be made on a capturing stream");
+        if ((rc = launch_wavefront(scene, S, C, P, d_sum_rgb, st, d_partials)) != RT_OK) return rc;
+    } else if ((opts->flags & RT_RENDER_KERNEL_LOCKSTEP) && !d_dump) {
         if ((rc = resident_blocks(scene, true, false, 0, &per_cu)) != RT_OK) return rc;
         hipLaunchKernelGGL(render_kernel, grid_for(per_cu, kBlock), dim3(kBlock), stack_bytes(scene), st, S, C, P, depth_slots,
                            d_sum_rgb, d_partials, d_work_counter);

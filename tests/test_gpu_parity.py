@@ -263,6 +263,54 @@ def test_all_render_schedules_give_the_same_image(scene1, rt):
     assert np.allclose(a, ordered_sum(6), rtol=2e-6, atol=1e-6)  # the chunking only reorders an f32 sum
 
 
+def test_wavefront_renderer_gives_the_same_image(scene1, rt, earth_rgb8, monkeypatch):
+    """RT_RENDER_KERNEL_WAVEFRONT: generate / trace / shade kernels that hand rays on through queues in device memory,
+    compacted by the material they hit.  Every path is the persistent kernel's path (same counters, same arithmetic)
+    and a pixel's samples are added in the same order, so the two images must be equal bit for bit: tree in LDS, tree
+    in HBM, no tree (nested shells), discs + emitter + texture map; one batch and many; accumulation on top."""
+    import os
+
+    from conftest import GOLDEN
+    from raytracer_amd import _abi
+
+    wf = _abi.RT_RENDER_KERNEL_WAVEFRONT
+    cam = rt.default_camera(200, 120)
+    a, _ = scene1.render(cam, 6, depth=50, seed=8)
+    b, _ = scene1.render(cam, 6, depth=50, seed=8, flags=wf)
+    assert np.array_equal(a, b)
+    for chunk in (1, 4):
+        c, _ = scene1.render(cam, 6, depth=50, seed=8, samples_per_item=chunk)
+        d, _ = scene1.render(cam, 6, depth=50, seed=8, samples_per_item=chunk, flags=wf)
+        assert np.array_equal(c, d)
+    # depth 0 (every path returns white) and depth 1
+    for depth in (0, 1):
+        c, _ = scene1.render(cam, 3, depth=depth, seed=1)
+        d, _ = scene1.render(cam, 3, depth=depth, seed=1, flags=wf)
+        assert np.array_equal(c, d)
+    # a pool of 6 * 1000 slots: 24 batches of 1000 pixels
+    monkeypatch.setenv("RT_WF_SLOTS", "6000")
+    fresh = rt.Scene(rt.gen_scene(1))
+    e, _ = fresh.render(cam, 6, depth=50, seed=8, flags=wf)
+    assert np.array_equal(a, e)
+    monkeypatch.delenv("RT_WF_SLOTS")
+    grid = rt.Scene(rt.gen_scene_grid(2, 48))  # tree in HBM
+    assert grid.info["lds_resident"] == 0
+    gcam = rt.Camera.build([0, 0, 0], [8, 3, 2], 1.0, 0.05, 96, 64)
+    f, _ = grid.render(gcam, 4, depth=50, seed=3)
+    g, _ = grid.render(gcam, 4, depth=50, seed=3, flags=wf)
+    assert np.array_equal(f, g)
+    shells = rt.Scene(rt.gen_scene_shells(6), [earth_rgb8])  # no tree: every sphere is tested per segment
+    scam = rt.Camera.build([0, 0, 1], [0, 1.5, -5], 1.0, 0.1, 96, 96)
+    h, _ = shells.render(scam, 4, depth=50, seed=2)
+    i, _ = shells.render(scam, 4, depth=50, seed=2, flags=wf)
+    assert np.array_equal(h, i)
+    cfg = rt.Config.from_json(os.path.join(GOLDEN, "scene.json"))  # disc, emitter, texture map
+    bundled = rt.Scene(cfg.hittables, cfg.textures)
+    j, _ = bundled.render(scam, 4, depth=10, seed=0)
+    k, _ = bundled.render(scam, 4, depth=10, seed=0, flags=wf)
+    assert np.array_equal(j, k)
+
+
 def test_work_hand_out_covers_every_pixel_sample_once(scene1, rt):
     """Eight work counters, tiles that hang over the frame's edge, frames smaller than a tile, waves that find their
     counter dry and move on, bands (tree in HBM) and interleaved items (scene in LDS): whatever the frame, the image is
