@@ -28,6 +28,21 @@ def test_library_exports_every_declared_symbol(rt):
     assert _abi.lib.rt_abi_version() >> 16 == 1
 
 
+def test_python_constants_match_the_header(rt):
+    """Every RT_* enumerator of include/rt_mi355x.h that the ctypes mirror names has the header's value."""
+    import os
+    import re
+
+    from raytracer_amd import _abi
+
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "rt_mi355x.h")).read()
+    found = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"\b(RT_[A-Z0-9_]+)\s*=\s*(-?(?:0x[0-9a-fA-F]+|\d+))\b", text)}
+    checked = [name for name in found if hasattr(_abi, name)]
+    assert len(checked) >= 20 and "RT_RENDER_KERNEL_WAVEFRONT" in checked
+    for name in checked:
+        assert getattr(_abi, name) == found[name], name
+
+
 def test_struct_sizes_match_oracle_layout(rt, ob):
     from raytracer_amd import _abi
 
