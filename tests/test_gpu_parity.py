@@ -309,6 +309,29 @@ def test_wavefront_renderer_gives_the_same_image(scene1, rt, earth_rgb8, monkeyp
     j, _ = bundled.render(scam, 4, depth=10, seed=0)
     k, _ = bundled.render(scam, 4, depth=10, seed=0, flags=wf)
     assert np.array_equal(j, k)
+    # samples [0, 3) and then [3, 6) on top, on the device, one chunk and several: the sums meet the same way
+    import ctypes as C
+
+    import hip_mem
+
+    for chunk in (0, 2):
+        sums = []
+        for flags in (0, wf):
+            d = hip_mem.DeviceArray(120 * 200 * 3)
+            for (s0, s1, acc) in ((0, 3, 0), (3, 6, _abi.RT_RENDER_ACCUMULATE)):
+                o = scene1.opts(s0, s1, 50, 8, flags | acc, chunk)
+                assert _abi.lib.rt_render_device(scene1.handle, C.byref(cam.c), C.byref(o), d.ptr, None) == 0, _abi.lib.rt_last_error()
+            sums.append(d.numpy().reshape(120, 200, 3))
+            d.free()
+        assert np.array_equal(sums[0], sums[1])
+        whole, _ = scene1.render(cam, 6, depth=50, seed=8, samples_per_item=chunk)
+        assert np.allclose(sums[1], whole, rtol=2e-6, atol=1e-6)
+    # the entry point that allocates nothing refuses it: the path pool is memory of the scene's own
+    d = hip_mem.DeviceArray(120 * 200 * 3)
+    o = scene1.opts(0, 2, 5, 0, wf, 0)
+    rc = _abi.lib.rt_render_device_noalloc(scene1.handle, C.byref(cam.c), C.byref(o), d.ptr, None)
+    d.free()
+    assert rc == _abi.RT_ERR_INVALID_ARGUMENT
 
 
 def test_work_hand_out_covers_every_pixel_sample_once(scene1, rt):
