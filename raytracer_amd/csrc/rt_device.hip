@@ -2871,6 +2871,7 @@ size_t partials_needed(const RenderParams& P) {
 int launch_wavefront(rt_scene* scene, const SceneDev& S, const CamDev& C, const RenderParams& P, float* d_sum_rgb, hipStream_t st,
                      float* d_partials) {
     const uint32_t spp = P.sample_end - P.sample_begin;
+    if (P.depth > 4096) return fail(RT_ERR_LIMIT, "wavefront render: depth %u beyond 4096 (two launches and 10 KB of queue lengths per bounce)", P.depth);
     uint32_t max_slots = kWfMaxSlots;
     if (const char* e = std::getenv("RT_WF_SLOTS")) max_slots = uint32_t(std::min<long long>(std::max<long long>(std::atoll(e), 1), kWfMaxSlots));  // test aid: small pools, many batches
     if (spp > max_slots) return fail(RT_ERR_LIMIT, "wavefront render: %u samples per pixel exceed the pool of %u path slots", spp, max_slots);

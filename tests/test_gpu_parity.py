@@ -309,6 +309,13 @@ def test_wavefront_renderer_gives_the_same_image(scene1, rt, earth_rgb8, monkeyp
     j, _ = bundled.render(scam, 4, depth=10, seed=0)
     k, _ = bundled.render(scam, 4, depth=10, seed=0, flags=wf)
     assert np.array_equal(j, k)
+    # no hittable at all, and a lone sphere
+    for hs in (rt.hittables([]), rt.hittables([rt.sphere([0, 0.2, 3.0], 0.75, rt.metal([0.8, 0.6, 0.2], 0.3))])):
+        tiny = rt.Scene(hs)
+        tcam = rt.Camera.build([0, 0.2, 3.0], [0, 1.5, -5], 1.0, 0.0, 40, 24)
+        m, _ = tiny.render(tcam, 3, depth=10, seed=5)
+        n, _ = tiny.render(tcam, 3, depth=10, seed=5, flags=wf)
+        assert np.array_equal(m, n)
     # samples [0, 3) and then [3, 6) on top, on the device, one chunk and several: the sums meet the same way
     import ctypes as C
 
