@@ -1683,9 +1683,8 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const float* __restric
 // samples + sample), a queue holds slot numbers, and a frame larger than the pool is rendered in batches of whole
 // pixels.  Every path is traced with the arithmetic of the persistent kernel (same Philox counters, same functions),
 // and a pixel's samples are added in the same order and chunk grouping, so the image equals render_kernel_ws's bit
-// for bit.  Measured against it on the bench scene the pipeline is several times slower (each segment writes and
-// reads its ray, hit and throughput through HBM and every bounce costs two launches): it is kept as the measured
-// alternative, not as the default.
+// for bit.  Measured against it on the bench scene the pipeline is four times slower (each segment writes and reads
+// its ray, hit and throughput through HBM): it is kept as the measured alternative, not as the default.
 struct WfState {
     double* ray;       // 6 per slot: origin, unit direction
     float* thr;        // 3 per slot: throughput
@@ -1703,13 +1702,14 @@ constexpr int kWfClasses = 4;  // 0 miss / emitter (the path ends), 1 diffuse / 
 // serves about 90 atomics per microsecond; a 1080p / 100 spp frame makes 13 M wave-level appends per queue).
 constexpr int kWfSub = 16;
 constexpr uint32_t kWfMaxSlots = 1u << 25;
+constexpr uint32_t kWfQueuedBounces = 10;  // bounces that go through the queues; wf_finish_kernel takes what is left
 // A sub-queue receives what the workgroups of one residue class produce, at most 1 / kWfSub of the entries plus one
 // 64-entry block per wave of the grid: room for that share and 65536 entries more.
 constexpr uint32_t kWfSubMargin = 65536;
 constexpr uint32_t kWfCountWords = 32;  // words between two length words (128 bytes)
 constexpr uint32_t kWfCountsPerBounce = (1 + kWfClasses) * kWfSub * kWfCountWords;
 // length word of sub-queue `sub` of queue q (0 = rays to trace, 1 + c = class c to shade) of bounce b; the very last
-// word block of the array (bounce depth + 1) is an overflow flag
+// word block of the array (one past the last bounce that is queued) is an overflow flag
 __device__ __forceinline__ uint32_t* wf_count(const WfState& W, uint32_t bounce, uint32_t q, uint32_t sub) {
     return W.counts + size_t(bounce) * kWfCountsPerBounce + (q * kWfSub + sub) * kWfCountWords;
 }
@@ -1824,7 +1824,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             const uint32_t pos = wf_append(wf_count(W, bounce, 1 + c, my_sub), mine);
             if (mine) {
                 if (pos < W.sub_cap) W.matq[(size_t(c) * kWfSub + my_sub) * W.sub_cap + pos] = slot;
-                else *wf_count(W, P.depth + 1, 0, 0) = 1u;  // cannot happen by the sizing of the sub-queues; never write past one
+                else *wf_count(W, min(P.depth, kWfQueuedBounces) + 1, 0, 0) = 1u;  // cannot happen by the sizing of the sub-queues; never write past one
             }
         }
     }
@@ -1881,8 +1881,38 @@ __global__ __launch_bounds__(kBlock) void wf_shade_kernel(SceneDev S, RenderPara
         const uint32_t pos = wf_append(wf_count(W, bounce + 1, 0, my_sub), alive);
         if (alive) {
             if (pos < W.sub_cap) W.rayq[size_t(my_sub) * W.sub_cap + pos] = slot;
-            else *wf_count(W, P.depth + 1, 0, 0) = 1u;
+            else *wf_count(W, min(P.depth, kWfQueuedBounces) + 1, 0, 0) = 1u;
         }
+    }
+}
+
+// The last stage of the pipeline: what is still alive after `bounce` bounces (a fraction of a percent of the paths
+// from the tenth bounce on) is followed to its end by one lane per path, the way trace_paths_kernel follows a path —
+// forty more pairs of nearly empty launches per batch cost more than this one.
+__global__ __launch_bounds__(kBlock) void wf_finish_kernel(SceneDev S, RenderParams P, WfState W, uint32_t pixel0, uint32_t bounce) {
+    extern __shared__ int32_t stack_lds[];
+    int32_t* stk = stack_lds + threadIdx.x;
+    __shared__ uint32_t seg_len[kWfSub], seg_end[kWfSub];
+    wf_segments(W, bounce, 0, kWfSub, seg_len, seg_end);
+    const uint32_t spp = P.sample_end - P.sample_begin;
+    const uint32_t total = seg_end[kWfSub - 1];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t waves = gridDim.x * (kBlock / 64);
+    for (uint32_t g0 = (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 64u; g0 < total; g0 += waves * 64u) {
+        const uint32_t seg = wf_segment_of(seg_end, kWfSub, g0);
+        const uint32_t j = g0 - (seg ? seg_end[seg - 1] : 0u) + lane;
+        if (j >= seg_len[seg]) continue;
+        const uint32_t slot = W.rayq[size_t(seg) * W.sub_cap + j];
+        const double* r = W.ray + 6 * size_t(slot);
+        const float* th = W.thr + 3 * size_t(slot);
+        Path p;
+        p.ox = r[0]; p.oy = r[1]; p.oz = r[2]; p.dx = r[3]; p.dy = r[4]; p.dz = r[5];
+        p.tr = th[0]; p.tg = th[1]; p.tb = th[2];
+        p.pixel = pixel0 + slot / spp; p.sample = P.sample_begin + slot % spp; p.bounce = bounce + 1;
+        float Lr, Lg, Lb;
+        while (advance(S, P, p, stk, Lr, Lg, Lb)) {}
+        float* o = W.colour + 3 * size_t(slot);
+        o[0] = Lr; o[1] = Lg; o[2] = Lb;
     }
 }
 
@@ -2866,18 +2896,17 @@ size_t partials_needed(const RenderParams& P) {
 
 // RT_RENDER_KERNEL_WAVEFRONT: the render as a pipeline of kernels with queues in HBM (see wf_trace_kernel).  The pool
 // of path slots belongs to the scene and is made on first use (104 bytes per slot, at most 2^25 slots = 3.5 GB); a
-// frame with more paths is rendered in batches of whole pixels.  Per batch: one generate, depth x (trace + shade), one
-// accumulate; nothing comes back to the host in between (empty queues cost their launches).
+// frame with more paths is rendered in batches of whole pixels.  Per batch: one generate, min(depth, 10) x (trace +
+// shade), one finish for the paths that live longer, one accumulate; nothing comes back to the host in between.
 int launch_wavefront(rt_scene* scene, const SceneDev& S, const CamDev& C, const RenderParams& P, float* d_sum_rgb, hipStream_t st,
                      float* d_partials) {
     const uint32_t spp = P.sample_end - P.sample_begin;
-    if (P.depth > 4096) return fail(RT_ERR_LIMIT, "wavefront render: depth %u beyond 4096 (two launches and 10 KB of queue lengths per bounce)", P.depth);
     uint32_t max_slots = kWfMaxSlots;
     if (const char* e = std::getenv("RT_WF_SLOTS")) max_slots = uint32_t(std::min<long long>(std::max<long long>(std::atoll(e), 1), kWfMaxSlots));  // test aid: small pools, many batches
     if (spp > max_slots) return fail(RT_ERR_LIMIT, "wavefront render: %u samples per pixel exceed the pool of %u path slots", spp, max_slots);
     const uint64_t n_paths = uint64_t(P.n_pixels) * spp;
     const size_t slots = size_t(std::min<uint64_t>(n_paths, (max_slots / spp) * uint64_t(spp)));
-    const size_t count_bytes = (size_t(P.depth) + 2) * kWfCountsPerBounce * sizeof(uint32_t);
+    const size_t count_bytes = (size_t(std::min<uint32_t>(P.depth, kWfQueuedBounces)) + 2) * kWfCountsPerBounce * sizeof(uint32_t);
     const size_t sub_cap = (slots + kWfSub - 1) / kWfSub + kWfSubMargin;
     const size_t pool_bytes = slots * (48 + 8 + 12 + 12 + 4) + (1 + kWfClasses) * kWfSub * sub_cap * sizeof(uint32_t) + 256;
     if (scene->wf_slots < slots || !scene->d_wf) {
@@ -2921,11 +2950,14 @@ int launch_wavefront(rt_scene* scene, const SceneDev& S, const CamDev& C, const 
         const uint32_t full = grid_of(8), trace_grid = grid_of(5);
         RT_HIP(hipMemsetAsync(W.counts, 0, count_bytes, st));
         hipLaunchKernelGGL(wf_generate_kernel, dim3(full), dim3(kBlock), 0, st, C, P, W, pixel0, n);
-        for (uint32_t b = 0; b < P.depth; ++b) {
+        const uint32_t queued_bounces = std::min<uint32_t>(P.depth, kWfQueuedBounces);
+        for (uint32_t b = 0; b < queued_bounces; ++b) {
             if (lds16) hipLaunchKernelGGL(wf_trace_kernel<true>, dim3(trace_grid), dim3(kBlock), trace_lds, st, S, P, W, scene->d_nodes16, b);
             else hipLaunchKernelGGL(wf_trace_kernel<false>, dim3(trace_grid), dim3(kBlock), trace_lds, st, S, P, W, static_cast<const Node16*>(nullptr), b);
             hipLaunchKernelGGL(wf_shade_kernel, dim3(full), dim3(kBlock), 0, st, S, P, W, pixel0, b);
         }
+        if (queued_bounces < P.depth)
+            hipLaunchKernelGGL(wf_finish_kernel, dim3(trace_grid), dim3(kBlock), stack_bytes(scene), st, S, P, W, pixel0, queued_bounces);
         const uint32_t n_acc = npix * P.n_chunks;
         hipLaunchKernelGGL(wf_accumulate_kernel, dim3((n_acc + kBlock - 1) / kBlock), dim3(kBlock), 0, st, P, W, pixel0, npix, d_sum_rgb, d_partials);
         RT_HIP(hipGetLastError());
