@@ -1048,7 +1048,7 @@ __device__ __forceinline__ void inner_step(const SceneDev& S, const uint4* lds_q
 //   * the lane masks go straight into EXEC where they are needed once (s_and / s_andn2 with EXEC as destination);
 //   * the loop's back edge is the conditional branch of the "enough lanes left" test.
 // Per step: 2 reads + wait, 18 slab + 2 min + 4 max3 / min3, 3 compares + 3 scalar + 3 selects, 7 for the stack,
-// 7 for the test and the masks = 49 (round 2: 56).
+// 7 for the test and the masks = 49 (an earlier form of the loop: 56).
 // Fixed registers: v112-v127 and s88-s99 are scratch of this block (the 128-bit node halves need named registers,
 // inline-asm operands cannot name the dwords of a tuple).  EXEC is narrowed inside and restored before leaving.
 #define RT_STR2(x) #x
