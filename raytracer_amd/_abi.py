@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librt_mi355x.so")
+LIB_PATH = os.environ.get("RT_MI355X_LIB") or os.path.join(_HERE, "lib", "librt_mi355x.so")  # the variable: another build of the library, for A/B measurements
 
 RT_OK = 0
 RT_ERR_INVALID_ARGUMENT, RT_ERR_UNSUPPORTED, RT_ERR_DEVICE, RT_ERR_IO, RT_ERR_LIMIT = 1, 2, 3, 4, 5
