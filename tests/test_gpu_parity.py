@@ -507,6 +507,54 @@ def _render_paths_against_oracle(scene, oscene, cam, ocam, ob, spp, depth, seed,
     return got, want, close, calm
 
 
+def test_tree_scene_with_disc_emitter_and_texture_runs_the_full_build(rt, ob, earth_rgb8):
+    """The production kernel exists twice: a lean build for scenes of plain spheres and the full one.  The bench
+    scene plus a disc, an emitter and a textured sphere is a scene WITH a tree that needs the full build: nearest hits
+    against the oracle's scan, the image against the ordered sum of its own per-path dump and against the wavefront
+    renderer, and the plain scene's two builds (RT_NO_PLAIN in the environment of a second scene) against one another."""
+    import os
+
+    from raytracer_amd import _abi
+
+    base = rt.gen_scene(1)
+    extra = rt.hittables([
+        rt.sphere([6.0, 0.6, 2.5], 0.6, rt.texture_map(0, [0, 1, -0.6], [1, 0, 0.5])),
+        rt.sphere([5.0, 2.2, 0.5], 0.4, rt.emitter([4.0, 3.5, 3.0])),
+        rt.disc([7.0, 0.6, 0.5], [0, 1, 0], 0.8, rt.metal([0.9, 0.9, 0.9], 0.05)),
+    ])
+    h = np.concatenate([base, extra])
+    scene, oscene = rt.Scene(h, [earth_rgb8]), ob.Scene(h, [earth_rgb8])
+    assert scene.info["n_nodes"] > 0 and scene.info["n_discs"] == 1
+    cam = rt.default_camera(160, 96)
+    o, d = scene.generate_primary(cam, seed=0, pixel_begin=0, pixel_end=160 * 96)
+    ids, t, nrm = scene.trace_primary(o, d)
+    want_ids, want_t, want_n, _ = oscene.trace(o, d, ob.TRAVERSE_LINEAR)
+    _check_hits(ids, t, nrm, want_ids, want_t, want_n)
+    for added in range(len(base), len(base) + 3):  # the three additions are in the picture
+        assert (ids == added).any()
+    spp = 4
+    img, _ = scene.render(cam, spp, depth=20, seed=3)
+    cols = scene.render_paths(cam, spp, depth=20, seed=3).reshape(160 * 96, spp, 3)
+    chunk = scene.render_chunk(cam, spp)
+    total = np.zeros((160 * 96, 3), dtype=np.float32)
+    for c0 in range(0, spp, chunk):
+        part = np.zeros((160 * 96, 3), dtype=np.float32)
+        for k in range(c0, min(c0 + chunk, spp)):
+            part += cols[:, k, :]
+        total += part
+    assert np.array_equal(total.reshape(96, 160, 3), img)
+    wf, _ = scene.render(cam, spp, depth=20, seed=3, flags=_abi.RT_RENDER_KERNEL_WAVEFRONT)
+    assert np.array_equal(wf, img)
+    # the plain scene through both builds of its kernel
+    lean, _ = rt.Scene(base).render(cam, spp, depth=20, seed=3)
+    os.environ["RT_NO_PLAIN"] = "1"
+    try:
+        full, _ = rt.Scene(base).render(cam, spp, depth=20, seed=3)
+    finally:
+        del os.environ["RT_NO_PLAIN"]
+    assert np.array_equal(lean, full)
+
+
 def test_render_kernel_paths_lds_scene_against_oracle(scene1, oscene1, ob, rt):
     # the kernel of the bench workload: scene in LDS, f16 boxes, assembly inner loop
     assert scene1.info["lds_resident"] == 1
