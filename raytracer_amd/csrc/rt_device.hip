@@ -465,9 +465,11 @@ struct Surf {
 // it ends here with the colour (Lr,Lg,Lb): a miss (sky), an emitter, or the depth limit.  At the depth
 // limit the reference still calls scatter and then drops the ray (src/lib.rs:105, :134); with a
 // counter-based RNG that call has no effect on anything, so it is not made.
-// PLAIN: the scene holds spheres of the three common materials only (no disc, texture map or emitter): the branches
-// for the others are not compiled in.
-template <bool PLAIN = false>
+// LEAN: what the scene is known not to hold, so that the branches for it are not compiled in.  kLeanNoDiscs: no
+// disc; kLeanPlain: spheres of the three common materials only (no disc, texture map or emitter; in trav_begin also no
+// nested shells).
+constexpr int kLeanNone = 0, kLeanNoDiscs = 1, kLeanPlain = 2;
+template <int LEAN = kLeanNone>
 __device__ __forceinline__ bool hit_part(const SceneDev& S, const Tables& Tb, const RenderParams& P, Path& p, const Best& hit,
                                          Surf& sf, float& Lr, float& Lg, float& Lb) {
 #pragma clang fp contract(off)
@@ -484,12 +486,13 @@ __device__ __forceinline__ bool hit_part(const SceneDev& S, const Tables& Tb, co
     const int32_t kind_word = Tb.kind[k];
     const float4 m = Tb.mat[k];
     double4 s = make_double4(0.0, 0.0, 0.0, 1.0);
-    if (PLAIN || k < S.n_spheres) s = Tb.sph[k];  // (a disc's index lies beyond the sphere table, which may be empty)
+    constexpr bool PLAIN = LEAN == kLeanPlain, NODISC = LEAN != kLeanNone;
+    if (NODISC || k < S.n_spheres) s = Tb.sph[k];  // (a disc's index lies beyond the sphere table, which may be empty)
     sf.hx = p.ox + hit.t * p.dx;  // scatter_loc = orig + t*dir (src/ray.rs:12-14)
     sf.hy = p.oy + hit.t * p.dy;
     sf.hz = p.oz + hit.t * p.dz;
     float lx, ly, lz;  // obj_relative_loc (src/lib.rs:106-113)
-    if (PLAIN || k < S.n_spheres) {
+    if (NODISC || k < S.n_spheres) {
         const float rx = float(sf.hx - s.x), ry = float(sf.hy - s.y), rz = float(sf.hz - s.z);
         const float inv_r = fast_rcp(float(s.w));
         sf.nx = rx * inv_r; sf.ny = ry * inv_r; sf.nz = rz * inv_r;  // src/geometry.rs:123-125
@@ -510,7 +513,7 @@ __device__ __forceinline__ bool hit_part(const SceneDev& S, const Tables& Tb, co
             Lr = m.x * c; Lg = m.y * c; Lb = m.z * c;
             return false;
         }
-        if (k < S.n_spheres) normalize3(lx, ly, lz);  // spheres: normalised, discs: as is (src/lib.rs:108-111)
+        if (NODISC || k < S.n_spheres) normalize3(lx, ly, lz);  // spheres: normalised, discs: as is (src/lib.rs:108-111)
         texture_albedo(S, kind_word >> 8, lx, ly, lz, &ar, &ag, &ab);
     }
     p.tr *= ar; p.tg *= ag; p.tb *= ab;
@@ -848,15 +851,16 @@ __device__ __forceinline__ bool sphere_candidate(const double4 s, int32_t k, con
 // box, step = a power of two that brings the half extent to about 1024, inside f16's normal range whatever the
 // scene's scale).
 // TREE = false: the scene has no tree (a handful of spheres, all tested here): there is no descent to set up.
-// PLAIN: no discs and no nested shells (see hit_part).
-template <bool GRID, bool TREE = true, bool PLAIN = false>
+// LEAN: see hit_part.
+template <bool GRID, bool TREE = true, int LEAN = kLeanNone>
 __device__ __forceinline__ void trav_begin(const SceneDev& S, const Tables& Tb, const Path& p, Trav& T, uint32_t slot1_addr, int32_t root) {
     T.best.t = 0.0;
     T.best.k = -1;
     T.best.id = 0x7fffffff;
     T.sp = slot1_addr;
     T.top = kLeafSentinel;
-    for (int32_t i = 0; !PLAIN && i < S.n_discs; ++i) {
+    constexpr bool PLAIN = LEAN == kLeanPlain, NODISC = LEAN != kLeanNone;
+    for (int32_t i = 0; !NODISC && i < S.n_discs; ++i) {
         double t;
         if (disc_intersect_f64(S.discs[i], p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, &t)) {
             const int32_t k = S.n_spheres + i;  // consider() with the indices read only on a tie
@@ -864,7 +868,7 @@ __device__ __forceinline__ void trav_begin(const SceneDev& S, const Tables& Tb, 
         }
     }
     // a sphere parameter is always positive: nothing can beat a non-positive disc hit
-    const bool spheres_matter = PLAIN || !(T.best.k >= 0 && T.best.t <= 0.0);
+    const bool spheres_matter = NODISC || !(T.best.k >= 0 && T.best.t <= 0.0);
     // Nested shells (SceneDev::shell_first): of m concentric spheres a segment can only meet first one of four
     // (and which three of them suffice is decided per lane below).
     // Count the shells its origin lies outside of (c > 0 in src/geometry.rs:107; they are the `outside` smallest):
@@ -1335,8 +1339,9 @@ __device__ __forceinline__ uint64_t cycle_stamp() { return __builtin_amdgcn_s_me
 // workgroup has its own copy: 8 KB + 16 bytes a node, next to its stacks) and reads spheres and material tables
 // through L1 like the HBM-tree kernel does; with the fifth wave the scalar and LDS instructions of one wave issue
 // beside the vector instructions of another more often (bench scene: 10.32 -> 9.9 ms).
-// PLAIN = true: built for scenes of plain spheres (hit_part, trav_begin): what most renders are, the bench scene included.
-template <bool LDS16, int BLOCK, int MODE, bool TREE = true, bool FIVE = false, bool PLAIN = false>
+// LEAN: built for scenes known not to hold discs (kLeanNoDiscs) or anything but plain spheres (kLeanPlain: what most
+// renders are, the bench scene included), see hit_part and trav_begin.
+template <bool LDS16, int BLOCK, int MODE, bool TREE = true, bool FIVE = false, int LEAN = kLeanNone>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FIVE ? 5 : 4, TREE ? (FIVE ? 5 : 4) : 8))) void render_kernel_ws(SceneDev S, CamDev C, RenderParams P,
                                                           const Node16* __restrict__ nodes16, uint32_t stack_depth,
                                                           float* __restrict__ sum_rgb, float* __restrict__ partials,
@@ -1430,7 +1435,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FIVE ? 5 
             bool fresh = false;
             if (alive) {
                 float Lr, Lg, Lb;
-                if (!hit_part<PLAIN>(S, Tb, P, p, T.best, sf, Lr, Lg, Lb)) {
+                if (!hit_part<LEAN>(S, Tb, P, p, T.best, sf, Lr, Lg, Lb)) {
                     ar += Lr; ag += Lg; ab += Lb;
                     alive = false;
                     if (DUMP) {
@@ -1493,7 +1498,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FIVE ? 5 
                     normalize3(d[0], d[1], d[2]);
                     p.ox = ox; p.oy = oy; p.oz = oz;
                     unit_f64(d[0], d[1], d[2], &p.dx, &p.dy, &p.dz);
-                    trav_begin<!LDS16, TREE, PLAIN>(S, Tb, p, T, slot1_addr, LDS16 ? int32_t(q0_addr) : 0);
+                    trav_begin<!LDS16, TREE, LEAN>(S, Tb, p, T, slot1_addr, LDS16 ? int32_t(q0_addr) : 0);
                 }
             }
         }
@@ -1957,6 +1962,7 @@ struct rt_scene {
     uint32_t* d_work_counter = nullptr;
     float* d_partials = nullptr;        // partial-sum slots of chunked renders, grown on demand
     bool plain = false;                 // spheres of the three common materials only, no nested shells: the production kernel's lean build
+    bool no_discs = false;              // no disc in the scene (the lean build of the kernel for scenes without a tree)
     unsigned char* d_wf = nullptr;      // path pool and queues of the wavefront renderer (RT_RENDER_KERNEL_WAVEFRONT), made on first use
     size_t wf_slots = 0;
     uint32_t* d_wf_counts = nullptr;    // its queue lengths, eight words per bounce
@@ -2101,15 +2107,20 @@ struct DeviceGuard {
 };
 
 typedef void (*ws_kernel_t)(SceneDev, CamDev, RenderParams, const Node16*, uint32_t, float*, float*, uint32_t*, float*);
-ws_kernel_t ws_kernel(bool lds16, int mode, bool tree = true, bool five = false, bool plain = false) {
-    // the production build for scenes of plain spheres (the statistics and dump builds keep every branch)
+ws_kernel_t ws_kernel(bool lds16, int mode, bool tree = true, bool five = false, bool plain = false, bool no_discs = false) {
+    // the production builds for scenes known not to hold discs, or anything but plain spheres (the statistics and dump
+    // builds keep every branch)
     if (plain && tree && mode == kModeProduction) {
-        if (lds16) return five ? render_kernel_ws<true, kBlock, kModeProduction, true, true, true> : render_kernel_ws<true, kBlockLds, kModeProduction, true, false, true>;
-        return five ? render_kernel_ws<false, kBlock, kModeProduction, true, true, true> : render_kernel_ws<false, kBlock, kModeProduction, true, false, true>;
+        if (lds16) return five ? render_kernel_ws<true, kBlock, kModeProduction, true, true, kLeanPlain> : render_kernel_ws<true, kBlockLds, kModeProduction, true, false, kLeanPlain>;
+        return five ? render_kernel_ws<false, kBlock, kModeProduction, true, true, kLeanPlain> : render_kernel_ws<false, kBlock, kModeProduction, true, false, kLeanPlain>;
+    }
+    if (no_discs && !plain && tree && mode == kModeProduction) {  // e.g. spheres with a texture map or an emitter among them
+        if (lds16) return five ? render_kernel_ws<true, kBlock, kModeProduction, true, true, kLeanNoDiscs> : render_kernel_ws<true, kBlockLds, kModeProduction, true, false, kLeanNoDiscs>;
+        return five ? render_kernel_ws<false, kBlock, kModeProduction, true, true, kLeanNoDiscs> : render_kernel_ws<false, kBlock, kModeProduction, true, false, kLeanNoDiscs>;
     }
     if (plain && tree && mode == kModeTiming) {  // the cycle stamps go around the production build's own phases
-        if (lds16) return five ? render_kernel_ws<true, kBlock, kModeTiming, true, true, true> : render_kernel_ws<true, kBlockLds, kModeTiming, true, false, true>;
-        return five ? render_kernel_ws<false, kBlock, kModeTiming, true, true, true> : render_kernel_ws<false, kBlock, kModeTiming, true, false, true>;
+        if (lds16) return five ? render_kernel_ws<true, kBlock, kModeTiming, true, true, kLeanPlain> : render_kernel_ws<true, kBlockLds, kModeTiming, true, false, kLeanPlain>;
+        return five ? render_kernel_ws<false, kBlock, kModeTiming, true, true, kLeanPlain> : render_kernel_ws<false, kBlock, kModeTiming, true, false, kLeanPlain>;
     }
     if (lds16 && tree && five) {
         switch (mode) {
@@ -2127,6 +2138,8 @@ ws_kernel_t ws_kernel(bool lds16, int mode, bool tree = true, bool five = false,
         default: return render_kernel_ws<false, kBlock, kModeProduction, true, true>;
         }
     }
+    if (lds16 && !tree && no_discs && mode == kModeProduction) return render_kernel_ws<true, kBlock, kModeProduction, false, false, kLeanNoDiscs>;
+    if (lds16 && !tree && no_discs && mode == kModeTiming) return render_kernel_ws<true, kBlock, kModeTiming, false, false, kLeanNoDiscs>;
     if (lds16 && !tree) {
         switch (mode) {
         case kModeStats: return render_kernel_ws<true, kBlock, kModeStats, false>;
@@ -2162,9 +2175,9 @@ int use_five_waves(rt_scene* sc, bool lds16, bool* five) {
     if (state < 0) {
         int per_cu = 0;
         if (!lds16) {
-            RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ws_kernel(false, kModeProduction, true, true, sc->plain), kBlock, stack_bytes(sc)));
+            RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ws_kernel(false, kModeProduction, true, true, sc->plain, sc->no_discs), kBlock, stack_bytes(sc)));
         } else if (sc->lds16_five_bytes != 0) {
-            const ws_kernel_t k = ws_kernel(true, kModeProduction, true, true, sc->plain);
+            const ws_kernel_t k = ws_kernel(true, kModeProduction, true, true, sc->plain, sc->no_discs);
             RT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsPerCu / 2)));
             RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, kBlock, lds16_launch_bytes(sc->lds16_five_bytes, sc->stack_depth, kBlock)));
         }
@@ -2186,7 +2199,7 @@ int lds16_launch(rt_scene* sc, int mode, LdsLaunch* out) {
     const bool tree = sc->dev.n_nodes != 0;
     bool five = false;
     if (tree) { if (int rc = use_five_waves(sc, true, &five)) return rc; }
-    out->kernel = ws_kernel(true, mode, tree, five, sc->plain);
+    out->kernel = ws_kernel(true, mode, tree, five, sc->plain, sc->no_discs);
     // a scene without a tree runs the shade-only kernel: fewer registers, so 256-thread workgroups fill the SIMDs with
     // five waves or more instead of four
     out->block = (tree && !five) ? kBlockLds : kBlock;
@@ -2219,7 +2232,7 @@ int resident_blocks(rt_scene* sc, bool lockstep, bool lds16, int mode, int* out)
         } else {
             bool five = false;
             if (int rc = use_five_waves(sc, false, &five)) return rc;
-            RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ws_kernel(false, mode, true, five, sc->plain), kBlock, stack_bytes(sc)));
+            RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ws_kernel(false, mode, true, five, sc->plain, sc->no_discs), kBlock, stack_bytes(sc)));
         }
         slot = per_cu < 1 ? 1 : per_cu;
     }
@@ -2845,7 +2858,8 @@ int rt_scene_create_ex(const rt_hittable* hittables, size_t n_hittables, const r
     sc->dev.n_discs = int32_t(n_d);
     sc->plain = n_d == 0 && shell_count == 0 && h_texmat.empty();
     for (size_t i = 0; i < n_hittables && sc->plain; ++i) sc->plain = hittables[i].material <= RT_MAT_DIELECTRIC;
-    if (std::getenv("RT_NO_PLAIN")) sc->plain = false;  // measurement aid: the build with every branch
+    sc->no_discs = n_d == 0;
+    if (std::getenv("RT_NO_PLAIN")) sc->plain = sc->no_discs = false;  // measurement aid: the build with every branch
     sc->dev.eps = 0.0f;
     sc->dev.eps_rel = 0.0f;
     {   // every surface's box against the two reference points of the relative descent
@@ -3031,7 +3045,7 @@ int launch_render(rt_scene* scene, const rt_camera* cam, const rt_render_opts* o
         if ((rc = resident_blocks(scene, false, false, mode, &per_cu)) != RT_OK) return rc;
         bool five = false;
         if ((rc = use_five_waves(scene, false, &five)) != RT_OK) return rc;
-        hipLaunchKernelGGL(ws_kernel(false, mode, true, five, scene->plain), grid_for(per_cu, kBlock), dim3(kBlock), stack_bytes(scene), st, S, C, P,
+        hipLaunchKernelGGL(ws_kernel(false, mode, true, five, scene->plain, scene->no_discs), grid_for(per_cu, kBlock), dim3(kBlock), stack_bytes(scene), st, S, C, P,
                            static_cast<const Node16*>(nullptr), depth_slots, d_sum_rgb, d_partials, d_work_counter, d_dump);
     }
     RT_HIP(hipGetLastError());

@@ -545,6 +545,19 @@ def test_tree_scene_with_disc_emitter_and_texture_runs_the_full_build(rt, ob, ea
     assert np.array_equal(total.reshape(96, 160, 3), img)
     wf, _ = scene.render(cam, spp, depth=20, seed=3, flags=_abi.RT_RENDER_KERNEL_WAVEFRONT)
     assert np.array_equal(wf, img)
+    # without the disc the scene runs the build that leaves the disc code out: same identity
+    nodisc = rt.Scene(h[:-1], [earth_rgb8])
+    assert nodisc.info["n_nodes"] > 0 and nodisc.info["n_discs"] == 0
+    img2, _ = nodisc.render(cam, spp, depth=20, seed=3)
+    cols2 = nodisc.render_paths(cam, spp, depth=20, seed=3).reshape(160 * 96, spp, 3)
+    chunk2 = nodisc.render_chunk(cam, spp)
+    total2 = np.zeros((160 * 96, 3), dtype=np.float32)
+    for c0 in range(0, spp, chunk2):
+        part = np.zeros((160 * 96, 3), dtype=np.float32)
+        for k in range(c0, min(c0 + chunk2, spp)):
+            part += cols2[:, k, :]
+        total2 += part
+    assert np.array_equal(total2.reshape(96, 160, 3), img2)
     # the plain scene through both builds of its kernel
     lean, _ = rt.Scene(base).render(cam, spp, depth=20, seed=3)
     os.environ["RT_NO_PLAIN"] = "1"
