@@ -195,7 +195,7 @@ def main():
                          "frac": round(achieved / roofline.PEAK_FP32_TFLOPS, 5),
                          "traffic": traffic["bytes_per_launch"] if traffic else None,
                          "traffic_source": traffic["source"] if traffic else "not collected for this command line (the committed counter passes cover `bench.py` on one GPU)",
-                         "kernel": "render_kernel_ws<true, 256, 0, true, true, true> (+ combine_kernel, 0.09 ms)", "kernel_ms": round(render_ms, 3),
+                         "kernel": "render_kernel_ws<true, 256, 0, true, true, 2> (+ combine_kernel, 0.09 ms)", "kernel_ms": round(render_ms, 3),
                          "kernel_ms_source": "HIP events on the launching stream around rt_render_device, mean of the timed steps",
                          "algorithmic_flops_per_path": round(fpp, 1), "segments_per_path": seg,
                          "segments_per_path_source": "device: RT_RENDER_STATS launch of the same kernel outside the timed region"
