@@ -558,6 +558,21 @@ def test_tree_scene_with_disc_emitter_and_texture_runs_the_full_build(rt, ob, ea
             part += cols2[:, k, :]
         total2 += part
     assert np.array_equal(total2.reshape(96, 160, 3), img2)
+    # the same for a tree that is read from memory (grid of spheres + an emitter: the no-disc build of that kernel)
+    g = np.concatenate([rt.gen_scene_grid(2, 48), rt.hittables([rt.sphere([3.0, 4.0, 1.0], 1.5, rt.emitter([3.0, 3.0, 2.5]))])])
+    grid = rt.Scene(g)
+    assert grid.info["lds_resident"] == 0 and grid.info["n_discs"] == 0
+    gcam = rt.Camera.build([0, 0, 0], [8, 3, 2], 1.0, 0.05, 96, 64)
+    img3, _ = grid.render(gcam, spp, depth=20, seed=4)
+    cols3 = grid.render_paths(gcam, spp, depth=20, seed=4).reshape(96 * 64, spp, 3)
+    chunk3 = grid.render_chunk(gcam, spp)
+    total3 = np.zeros((96 * 64, 3), dtype=np.float32)
+    for c0 in range(0, spp, chunk3):
+        part = np.zeros((96 * 64, 3), dtype=np.float32)
+        for k in range(c0, min(c0 + chunk3, spp)):
+            part += cols3[:, k, :]
+        total3 += part
+    assert np.array_equal(total3.reshape(64, 96, 3), img3)
     # the plain scene through both builds of its kernel
     lean, _ = rt.Scene(base).render(cam, spp, depth=20, seed=3)
     os.environ["RT_NO_PLAIN"] = "1"
